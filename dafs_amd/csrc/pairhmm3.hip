@@ -1,0 +1,437 @@
+// dafs_amd/csrc/pairhmm3.hip -- batched ProbCons pair-HMM posteriors for gfx950.
+//
+// What it computes, per sequence pair (x,y) (reference file:line it replaces):
+//   forward / backward / posterior of the 3-state pair HMM   src/probconsRNA/ProbabilisticModel.h:105-403
+//   threshold + dense->sparse rows (p > th)                   src/probconsRNA/wrapper.cpp:125-128, src/align.cpp:69-78
+//   the transposed row lists mp[y][x]                         src/dafs.cpp:155-167
+//   the similarity score sim[x][y]                            src/dafs.cpp:713-764
+//
+// Mapping to the machine.  A group of G lanes (G = 16/32/64, so 4/2/1 pairs per wavefront)
+// owns one pair.  Lane t of the group owns the W consecutive columns j = t*W .. t*W+W-1 of the
+// (L1+1) x (L2+1) DP grid and keeps the previous row of its columns in registers; rows are
+// skewed so that at wavefront step s lane t works on row i = s - t (a register-resident
+// anti-diagonal wavefront: no LDS traffic and no barriers, the only cross-lane exchange is one
+// lane-to-neighbour shuffle of the boundary column per step).  Four sweeps share that shape:
+//   1 forward   : writes F_M(i,j) to the wave's slab in HBM
+//   2 backward  : mirrored skew; reads F_M, writes S = F_M + B_M in place
+//   3 posterior : P = EXP(min(0,S-total)) thresholded, written in place; the same sweep runs the
+//                 similarity-score DP and counts entries per row (count travels with the row
+//                 from lane to lane) and per column (registers)
+//   4 emit      : scatters the entries into the CSR of mp[x][y] and of mp[y][x]
+// The slab is indexed [(step*W + c)*64 + lane], so every slab access of a wave instruction is one
+// contiguous 256-byte segment, in all four sweeps (the backward sweep visits forward step
+// L1+G-1-s, the same for every lane).  Work is handed out by a device-side counter, longest
+// pairs first.
+//
+// Arithmetic is the reference's, operation for operation (pc_math.h); compile with
+// -ffp-contract=off.  Results are bit-identical to the CPU path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "../../include/dafs_hip.h"
+#include "pc_math.h"
+#include "hip_util.h"
+
+namespace dafs {
+
+template <int G>
+__device__ __forceinline__ float shfl_up1(float v) { return __shfl_up(v, 1, G); }
+template <int G>
+__device__ __forceinline__ int shfl_up1(int v) { return __shfl_up(v, 1, G); }
+template <int G>
+__device__ __forceinline__ float shfl_down1(float v) { return __shfl_down(v, 1, G); }
+
+template <int G, int W>
+__global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t slab_steps, uint32_t rp_cap) {
+  constexpr int NG = 64 / G;  // pairs per wavefront
+  extern __shared__ uint32_t s_dyn[];  // per (wave, group): rp_cap row pointers
+  __shared__ float s_match[56];
+  __shared__ float s_ins[8];
+  if (threadIdx.x < 56) s_match[threadIdx.x] = (&a.model.match[0][0])[threadIdx.x];
+  if (threadIdx.x < 8) s_ins[threadIdx.x] = a.model.ins[threadIdx.x];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int t = lane % G;
+  const int g = lane / G;
+  const int wave_in_wg = threadIdx.x >> 6;
+  const uint32_t wave = blockIdx.x * 4 + wave_in_wg;
+  float* __restrict__ slab = a.scratch + (size_t)wave * slab_steps * W * 64;
+  uint32_t* __restrict__ s_rowptr = s_dyn + (size_t)(wave_in_wg * NG + g) * rp_cap;
+
+  const float LZ = PC_LOG_ZERO;
+  const float i0 = a.model.init[0], i1 = a.model.init[1], i2 = a.model.init[2];
+  const float tMM = a.model.trans[0][0], tMX = a.model.trans[0][1], tMY = a.model.trans[0][2];
+  const float tXM = a.model.trans[1][0], tXX = a.model.trans[1][1];
+  const float tYM = a.model.trans[2][0], tYY = a.model.trans[2][2];
+  const float th = a.th;
+
+  for (;;) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(a.queue, (uint32_t)NG);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base >= a.ntasks) break;
+    const uint32_t task = base + g;
+    const bool act = task < a.ntasks;
+    dafs_pair_task tk = {0, 0, 0, 0};
+    if (act) tk = a.tasks[task];
+    const int L1 = act ? (int)tk.len1 : -1;
+    const int L2 = act ? (int)tk.len2 : -1;
+    const uint8_t* __restrict__ s1 = a.codes + tk.off1;
+    const uint8_t* __restrict__ s2 = a.codes + tk.off2;
+
+    // wave-uniform step count: max over the groups of this wave
+    int maxL1 = L1;
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) maxL1 = max(maxL1, __shfl_xor(maxL1, o));
+    const int nsteps = maxL1 + G;
+
+    // residue classes of this lane's columns: cc[c] = class of column j=t*W+c (s2[j-1]); 6 = other
+    int cc[W + 1];
+#pragma unroll
+    for (int c = 0; c <= W; ++c) {
+      const int j = t * W + c;
+      cc[c] = (j >= 1 && j <= L2) ? (int)s2[j - 1] : 6;
+    }
+    const int c1first = act ? (int)s1[0] : 6;
+    const int c2first = act ? (int)s2[0] : 6;
+    // the three initial cells (ProbabilisticModel.h:123-131)
+    const float fM11 = i0 + s_match[c1first * 8 + c2first];
+    const float fX10 = i1 + s_ins[c1first];
+    const float fY01 = i2 + s_ins[c2first];
+
+    // ------------------------------------------------------------------ sweep 1: forward
+    float totF = LZ;
+    {
+      float pM[W], pX[W], pY[W];
+#pragma unroll
+      for (int c = 0; c < W; ++c) pM[c] = pX[c] = pY[c] = LZ;
+      float lastM = LZ, lastX = LZ, lastY = LZ;  // this lane's last column, row of the previous step
+      float dgM = LZ, dgX = LZ, dgY = LZ;        // neighbour's last column, one row earlier
+      for (int s = 0; s < nsteps; ++s) {
+        const int i = s - t;
+        const bool rowv = (i >= 0) && (i <= L1);
+        const int c1 = (rowv && i >= 1) ? (int)s1[i - 1] : 6;
+        float rM = shfl_up1<G>(lastM), rX = shfl_up1<G>(lastX), rY = shfl_up1<G>(lastY);
+        if (t == 0) { rM = LZ; rX = LZ; rY = LZ; }
+        float dM = dgM, dX = dgX, dY = dgY;  // (i-1, j-1)
+        float lM = rM, lY = rY;              // (i, j-1)
+        const float insc1 = s_ins[c1];
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          const int j = t * W + c;
+          const bool v = rowv && (j <= L2);
+          const float mt = s_match[c1 * 8 + cc[c]];
+          // ProbabilisticModel.h:152-155
+          float m = dM + tMM;
+          m = pc_log_add(m, dX + tXM);
+          m = pc_log_add(m, dY + tYM);
+          m += mt;
+          // :159-161 and :165-167
+          float x = insc1 + pc_log_add(pM[c] + tMX, pX[c] + tXX);
+          float y = s_ins[cc[c]] + pc_log_add(lM + tMY, lY + tYY);
+          // initial cells, :123-131 (cells with i<=1 && j<=1 are not touched by the recursion, :150)
+          if (i <= 1 && j <= 1) {
+            m = (i == 1 && j == 1) ? fM11 : LZ;
+            x = (i == 1 && j == 0) ? fX10 : LZ;
+            y = (i == 0 && j == 1) ? fY01 : LZ;
+          }
+          if (!v) { m = LZ; x = LZ; y = LZ; }
+          dM = pM[c]; dX = pX[c]; dY = pY[c];
+          pM[c] = m; pX[c] = x; pY[c] = y;
+          lM = m; lY = y;
+          if (v) slab[(size_t)(s * W + c) * 64 + lane] = m;
+          if (v && i == L1 && j == L2) {  // ComputeTotalProbability, :341-347 (B_k(L1,L2) = init_k)
+            float tf = LZ;
+            tf = pc_log_add(tf, m + i0);
+            tf = pc_log_add(tf, x + i1);
+            tf = pc_log_add(tf, y + i2);
+            totF = tf;
+          }
+        }
+        dgM = rM; dgX = rX; dgY = rY;
+        lastM = pM[W - 1]; lastX = pX[W - 1]; lastY = pY[W - 1];
+      }
+    }
+    const int tlast = (L2 >= 0 ? L2 : 0) / W;  // lane (within group) that owns column L2
+    totF = __shfl(totF, g * G + tlast);
+
+    // ------------------------------------------------------------------ sweep 2: backward
+    float capM = LZ, capX = LZ, capY = LZ;  // B_M(1,1), B_X(1,0), B_Y(0,1)
+    {
+      float pM[W], pX[W];
+#pragma unroll
+      for (int c = 0; c < W; ++c) pM[c] = pX[c] = LZ;
+      float firstM = LZ, firstY = LZ;  // this lane's first column, row of the previous step
+      float dgM = LZ;                  // right neighbour's first column, one row later
+      for (int s = 0; s < nsteps; ++s) {
+        // mirrored skew: lane G-1 starts with the last row
+        const int i = L1 - s + (G - 1 - t);
+        const bool rowv = (i >= 0) && (i <= L1);
+        const int sf = i + t;  // forward step that stored row i for this lane (wave-uniform per group)
+        const int c1 = (rowv && i < L1) ? (int)s1[i] : 6;
+        float rM = shfl_down1<G>(firstM), rY = shfl_down1<G>(firstY);
+        if (t == G - 1) { rM = LZ; rY = LZ; }
+        float dM = dgM;  // B_M(i+1, j+1)
+        float rgY = rY;  // B_Y(i, j+1)
+        const float insc1 = s_ins[c1];
+        float fwd[W];
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          const int j = t * W + c;
+          fwd[c] = (rowv && j <= L2) ? slab[(size_t)(sf * W + c) * 64 + lane] : 0.0f;
+        }
+#pragma unroll
+        for (int c = W - 1; c >= 0; --c) {
+          const int j = t * W + c;
+          const bool v = rowv && (j <= L2);
+          const int c2 = cc[c + 1];  // class of s2[j] (iter2[j+1]); 'other' beyond the end
+          float bm = LZ, bx = LZ, by = LZ;
+          if (i == L1 && j == L2) { bm = i0; bx = i1; by = i2; }  // :213-214
+          // :233-237
+          const float pxy = dM + s_match[c1 * 8 + c2];
+          bm = pc_log_add(bm, pxy + tMM);
+          bx = pc_log_add(bx, pxy + tXM);
+          by = pc_log_add(by, pxy + tYM);
+          // :238-243
+          const float tx = pX[c] + insc1;
+          bm = pc_log_add(bm, tx + tMX);
+          bx = pc_log_add(bx, tx + tXX);
+          // :244-249
+          const float ty = rgY + s_ins[c2];
+          bm = pc_log_add(bm, ty + tMY);
+          by = pc_log_add(by, ty + tYY);
+          if (!v) { bm = LZ; bx = LZ; by = LZ; }
+          dM = pM[c];
+          pM[c] = bm; pX[c] = bx;
+          rgY = by;
+          if (v) slab[(size_t)(sf * W + c) * 64 + lane] = fwd[c] + bm;  // forward[ij] + backward[ij], :395
+          if (v && i == 1 && j == 1) capM = bm;
+          if (v && i == 1 && j == 0) capX = bx;
+          if (v && i == 0 && j == 1) capY = by;
+          if (c == 0) firstY = by;
+        }
+        dgM = rM;
+        firstM = pM[0];
+      }
+    }
+    // ComputeTotalProbability, :349-364
+    capM = __shfl(capM, g * G + (1 / W));
+    capX = __shfl(capX, g * G);
+    capY = __shfl(capY, g * G + (1 / W));
+    float totB = fM11 + capM;
+    totB = pc_log_add(totB, fX10 + capX);
+    totB = pc_log_add(totB, fY01 + capY);
+    const float total = (totF + totB) / 2;
+
+    // ------------------------------------------------------------------ sweep 3: posterior + sim + counts
+    int colcnt[W];
+    float simv = 0.0f;
+    uint32_t nnz = 0;
+    {
+      float pdp[W];
+      int ptr[W];
+#pragma unroll
+      for (int c = 0; c < W; ++c) { pdp[c] = 0.0f; ptr[c] = 0; colcnt[c] = 0; }
+      float lastdp = 0.0f, dgdp = 0.0f;
+      int lasttr = 0, dgtr = 0, lastcnt = 0;
+      uint32_t rowacc = 0;
+      if (t == G - 1) s_rowptr[0] = 0;
+      for (int s = 0; s < nsteps; ++s) {
+        const int i = s - t;
+        const bool rowv = (i >= 0) && (i <= L1);
+        float rdp = shfl_up1<G>(lastdp);
+        int rtr = shfl_up1<G>(lasttr), rcnt = shfl_up1<G>(lastcnt);
+        if (t == 0) { rdp = 0.0f; rtr = 0; rcnt = 0; }
+        float ddp = dgdp, ldp = rdp;
+        int dtr = dgtr, ltr = rtr, run = rcnt;
+        float sv[W];
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          const int j = t * W + c;
+          sv[c] = (rowv && j <= L2) ? slab[(size_t)(s * W + c) * 64 + lane] : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          const int j = t * W + c;
+          const bool v = rowv && (j <= L2);
+          const bool inner = v && i >= 1 && j >= 1;
+          // ComputePosteriorMatrix :395, wrapper.cpp:125-128 (>= th keeps), align.cpp:75 (> th keeps)
+          const float e = sv[c] - total;
+          const float p = pc_exp(e < 0.0f ? e : 0.0f);
+          const bool entry = inner && (p >= th) && (p > th);
+          if (v) slab[(size_t)(s * W + c) * 64 + lane] = entry ? p : 0.0f;
+          // calculate_similarity_score, dafs.cpp:720-760
+          const float udp = pdp[c];
+          const int utr = ptr[c];
+          float dp;
+          int tr;
+          if (entry) {
+            dp = ddp + p; tr = dtr + 1;
+            if (dp < ldp) { dp = ldp; tr = ltr + 1; }
+            if (dp < udp) { dp = udp; tr = utr + 1; }
+          } else {
+            dp = ldp; tr = ltr + 1;
+            if (dp < udp) { dp = udp; tr = utr + 1; }
+          }
+          if (!inner) { dp = 0.0f; tr = 0; }
+          ddp = udp; dtr = utr;
+          pdp[c] = dp; ptr[c] = tr;
+          ldp = dp; ltr = tr;
+          run += entry ? 1 : 0;
+          colcnt[c] += entry ? 1 : 0;
+          if (v && i == L1 && j == L2) simv = dp / (float)tr;  // dafs.cpp:763
+        }
+        dgdp = rdp; dgtr = rtr;
+        lastdp = pdp[W - 1]; lasttr = ptr[W - 1]; lastcnt = run;
+        if (t == G - 1 && rowv && i >= 1) {  // row i is complete: its count has crossed the group
+          rowacc += (uint32_t)run;
+          s_rowptr[i] = rowacc;
+        }
+      }
+      nnz = rowacc;
+    }
+    nnz = __shfl(nnz, g * G + (G - 1));
+    simv = __shfl(simv, g * G + tlast);
+
+    // column prefix sums (row pointers of the transposed matrix)
+    int colbase[W];
+    {
+      int mine = 0;
+#pragma unroll
+      for (int c = 0; c < W; ++c) mine += colcnt[c];
+      int incl = mine;
+#pragma unroll
+      for (int o = 1; o < G; o <<= 1) {
+        const int up = __shfl_up(incl, o, G);
+        if (t >= o) incl += up;
+      }
+      int run = incl - mine;
+#pragma unroll
+      for (int c = 0; c < W; ++c) { colbase[c] = run; run += colcnt[c]; }
+    }
+
+    // reserve 2*nnz entries in the pool
+    unsigned long long off = 0;
+    if (t == 0 && act) off = atomicAdd(a.pool_top, 2ull * nnz);
+    off = __shfl(off, g * G);
+    const bool ok = act && (off + 2ull * nnz <= a.pool_cap);
+    if (act && !ok && t == 0) atomicExch(a.status, DAFS_HIP_EOVERFLOW);
+    const uint64_t rp = act ? a.rp_off[task] : 0;
+    if (act && t == 0) {
+      a.pair_off[task] = off;
+      a.pair_nnz[task] = nnz;
+      a.sim[task] = simv;
+    }
+    wave_lds_fence();
+    // row pointers out (coalesced copy from LDS), transposed row pointers from registers
+    if (act) {
+      for (int r = t; r <= L1; r += G) a.rowptr_pool[rp + r] = s_rowptr[r];
+      if (t == 0) a.rowptr_pool[rp + L1 + 1] = 0;
+#pragma unroll
+      for (int c = 0; c < W; ++c) {
+        const int j = t * W + c;
+        if (j >= 1 && j <= L2) a.rowptr_pool[rp + L1 + 1 + j] = (uint32_t)(colbase[c] + colcnt[c]);
+      }
+    }
+
+    // ------------------------------------------------------------------ sweep 4: emit CSR + transposed CSR
+    if (__any(ok)) {
+      int colrun[W];
+#pragma unroll
+      for (int c = 0; c < W; ++c) colrun[c] = 0;
+      int lastcnt = 0;
+      for (int s = 0; s < nsteps; ++s) {
+        const int i = s - t;
+        const bool rowv = (i >= 0) && (i <= L1);
+        int rcnt = shfl_up1<G>(lastcnt);
+        if (t == 0) rcnt = 0;
+        int run = rcnt;
+        const uint32_t rowbase = (rowv && i >= 1) ? s_rowptr[i - 1] : 0;
+        float pv[W];
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          const int j = t * W + c;
+          pv[c] = (rowv && j <= L2) ? slab[(size_t)(s * W + c) * 64 + lane] : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          const int j = t * W + c;
+          const bool entry = pv[c] != 0.0f;
+          if (entry && ok) {
+            const unsigned long long pos = off + rowbase + (uint32_t)run;
+            a.ent_col[pos] = (uint32_t)(j - 1);
+            a.ent_val[pos] = pv[c];
+            const unsigned long long tpos = off + nnz + (uint32_t)(colbase[c] + colrun[c]);
+            a.ent_col[tpos] = (uint32_t)(i - 1);
+            a.ent_val[tpos] = pv[c];
+          }
+          run += entry ? 1 : 0;
+          colrun[c] += entry ? 1 : 0;
+        }
+        lastcnt = run;
+      }
+    }
+    wave_lds_fence();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+typedef void (*pairhmm3_fn)(dafs_pairhmm3_args, uint32_t, uint32_t);
+struct variant { int G, W; pairhmm3_fn fn; };
+#define V(G, W) {G, W, k_pairhmm3<G, W>}
+static const variant k_variants[] = {
+    V(16, 2), V(16, 3), V(16, 4), V(16, 5), V(16, 6), V(16, 8), V(16, 10), V(16, 11), V(16, 12), V(16, 14), V(16, 16),
+    V(32, 2), V(32, 3), V(32, 4), V(32, 5), V(32, 6), V(32, 8), V(32, 10), V(32, 12), V(32, 14), V(32, 16),
+    V(64, 1), V(64, 2), V(64, 3), V(64, 4), V(64, 5), V(64, 6), V(64, 8), V(64, 10), V(64, 12), V(64, 14), V(64, 16), V(64, 24), V(64, 32),
+};
+#undef V
+
+static const uint32_t kMaxWaves = 256 * 8;  // 256 CUs x 2 waves per SIMD
+
+}  // namespace dafs
+
+using namespace dafs;
+
+extern "C" int dafs_hipk_pairhmm_plan(uint32_t ntasks, uint32_t max_len1, uint32_t max_len2, dafs_pairhmm_plan* plan) {
+  if (!plan || ntasks == 0 || max_len1 == 0 || max_len2 == 0) return DAFS_HIP_EINVAL;
+  const variant* best = nullptr;
+  double best_cost = 0;
+  // DAFS_HIP_FORCE_GROUP=16|32|64 pins the lanes-per-pair choice (tests exercise every variant)
+  const char* force = getenv("DAFS_HIP_FORCE_GROUP");
+  const int force_g = force ? atoi(force) : 0;
+  for (const variant& v : k_variants) {
+    if ((uint64_t)v.G * v.W < (uint64_t)max_len2 + 1) continue;
+    if (force_g && v.G != force_g) continue;
+    const uint64_t waves = ((uint64_t)ntasks + (64 / v.G) - 1) / (64 / v.G);
+    const uint64_t rounds = (waves + kMaxWaves - 1) / kMaxWaves;
+    const double cost = (double)(max_len1 + v.G) * v.W * (double)rounds;
+    if (!best || cost < best_cost) { best = &v; best_cost = cost; }
+  }
+  if (!best) return DAFS_HIP_ETOOLONG;
+  const uint64_t waves = ((uint64_t)ntasks + (64 / best->G) - 1) / (64 / best->G);
+  plan->group = best->G;
+  plan->width = best->W;
+  uint32_t nw = (uint32_t)(waves < kMaxWaves ? waves : kMaxWaves);
+  nw = (nw + 3) & ~3u;  // whole workgroups of 4 waves
+  plan->nwaves = nw;
+  plan->slab_steps = max_len1 + best->G;
+  plan->scratch_bytes = (uint64_t)nw * plan->slab_steps * best->W * 64 * sizeof(float);
+  return DAFS_HIP_OK;
+}
+
+extern "C" int dafs_hipk_pairhmm3_launch(const dafs_pairhmm3_args* args, const dafs_pairhmm_plan* plan, void* hip_stream) {
+  if (!args || !plan) return DAFS_HIP_EINVAL;
+  if (args->ntasks == 0) return DAFS_HIP_OK;
+  const variant* v = nullptr;
+  for (const variant& c : k_variants)
+    if (c.G == (int)plan->group && c.W == (int)plan->width) v = &c;
+  if (!v || plan->nwaves % 4) return DAFS_HIP_EINVAL;
+  const uint32_t rp_cap = plan->slab_steps - plan->group + 1;  // max_len1 + 1 row pointers
+  const size_t lds = (size_t)4 * (64 / v->G) * rp_cap * sizeof(uint32_t);
+  if (lds > 60 * 1024) return DAFS_HIP_ETOOLONG;
+  hipLaunchKernelGGL(v->fn, dim3(plan->nwaves / 4), dim3(256), lds, (hipStream_t)hip_stream, *args, plan->slab_steps, rp_cap);
+  return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
+}

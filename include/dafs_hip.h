@@ -1,0 +1,137 @@
+/* include/dafs_hip.h -- C ABI of libdafs_hip.so, the MI355X (gfx950) implementation of the
+ * DAFS probability-matrix + dual-decomposition hot path.
+ *
+ * Two layers, both plain C (pointers + sizes, no C++/torch types):
+ *
+ *  L1 "plugin" entry points (dafs_hip_*): host buffers in, host buffers out.  These are what the
+ *     reference's four plugin interfaces would bind (reference src/align.h:34-66,
+ *     src/fold.h:30-61) -- see INTEGRATION.md for the C++ shim a DAFS maintainer would add.
+ *     They own their device workspace and synchronise before returning.
+ *
+ *  L0 "launch" entry points (dafs_hipk_*): device pointers + a HIP stream, no allocation, no
+ *     synchronisation.  Used by L1 and by callers that keep data resident in HBM (bench.py
+ *     allocates with torch and passes tensor.data_ptr()).
+ *
+ * All functions return 0 on success or a negative DAFS_HIP_E* code; no exception crosses the
+ * ABI.  dafs_hip_strerror() gives the message the C++ shim throws as `const char*`, the
+ * reference's error convention (reference src/dafs.cpp:1893-1910).
+ * Indices are uint32; "none" is 0xFFFFFFFF (the reference's -1u, src/nussinov.cpp:267).
+ */
+#ifndef DAFS_HIP_H
+#define DAFS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAFS_HIP_NONE 0xFFFFFFFFu
+
+enum {
+  DAFS_HIP_OK = 0,
+  DAFS_HIP_EINVAL = -1,    /* bad argument (NULL, empty sequence, unknown model) */
+  DAFS_HIP_ENODEV = -2,    /* no usable HIP device / HIP runtime error */
+  DAFS_HIP_ENOMEM = -3,    /* device or host allocation failed */
+  DAFS_HIP_ETOOLONG = -4,  /* sequence longer than the kernels support */
+  DAFS_HIP_EOVERFLOW = -5, /* sparse output pool too small (retry with a larger pool) */
+  DAFS_HIP_ELAUNCH = -6    /* kernel launch / execution failure */
+};
+const char* dafs_hip_strerror(int code);
+/* last HIP runtime error text seen by this thread (diagnostics) */
+const char* dafs_hip_last_error(void);
+
+/* Alignment models: reference -a ProbCons | CONTRAlign (src/dafs.cpp:1683-1690) */
+enum { DAFS_ALIGN_PROBCONS = 0, DAFS_ALIGN_CONTRALIGN = 1 };
+/* Folding models: reference -s CONTRAfold (src/dafs.cpp:1703).  Boltzmann/Vienna need
+ * ViennaRNA arithmetic that is not in the reference tree: not provided. */
+enum { DAFS_FOLD_CONTRAFOLD = 0 };
+
+/* ------------------------------------------------------------------------------------------
+ * L0: pair-HMM posterior kernel (ProbCons 3-state model)
+ * Replaces, per pair: PROBCONS::Probcons::ComputePosterior (src/probconsRNA/wrapper.cpp:101-131)
+ * + ProbCons::calculate's dense->sparse step (src/align.cpp:60-79) + transpose_mp
+ * (src/dafs.cpp:155-167) + calculate_similarity_score (src/dafs.cpp:713-764).
+ * ---------------------------------------------------------------------------------------- */
+
+/* One pair job: offsets/lengths of the two residue-code strings inside `codes`. */
+typedef struct {
+  uint32_t off1, len1; /* sequence x (rows)    */
+  uint32_t off2, len2; /* sequence y (columns) */
+} dafs_pair_task;
+
+/* Launch geometry chosen by dafs_hipk_pairhmm_plan for a batch. */
+typedef struct {
+  uint32_t group;        /* lanes cooperating on one pair: 16, 32 or 64           */
+  uint32_t width;        /* columns owned by each lane                              */
+  uint32_t nwaves;       /* persistent wavefronts launched (4 per workgroup)        */
+  uint32_t slab_steps;   /* wavefront steps one slab holds = max(len1)+group        */
+  uint64_t scratch_bytes;/* bytes of `scratch` the launch needs                     */
+} dafs_pairhmm_plan;
+
+/* 7 residue classes: A C G U T N other ('other' includes the reference's '~' sentinel). */
+typedef struct {
+  float init[3];     /* log initial distribution M, X, Y   (Defaults.h:19)                  */
+  float trans[3][3]; /* log transition [from][to]          (ProbabilisticModel.h:59-79)     */
+  float match[7][8]; /* log pair emission, row stride 8    (Defaults.h:30-37)               */
+  float ins[8];      /* log single emission                (Defaults.h:26-28)               */
+} dafs_pairhmm3_model;
+
+typedef struct {
+  const uint8_t* codes;        /* [device] residue class codes 0..6, all sequences concatenated */
+  const dafs_pair_task* tasks; /* [device] ntasks jobs, in processing order (longest first)      */
+  uint32_t ntasks;
+  float th;                    /* keep posterior > th (reference -u, default 0.01)               */
+  float* scratch;              /* [device] plan.scratch_bytes                                     */
+  uint32_t* queue;             /* [device] one zeroed uint32: dynamic work counter                */
+  /* outputs, all [device].  Pair t owns rowptr_pool[rp_off[t] .. +len1+1) (row pointers of
+   * mp[x][y], relative to the pair's base) followed by len2+1 row pointers of mp[y][x];
+   * entries live at ent_col/ent_val[pair_off[t] .. +nnz) (mp[x][y], rows ascending, columns
+   * ascending) and [pair_off[t]+nnz .. +2nnz) (mp[y][x]).  pair_off is assigned by a device-side
+   * bump allocator on *pool_top, so pool order is unspecified; contents are deterministic. */
+  const uint64_t* rp_off;
+  uint32_t* rowptr_pool;
+  uint32_t* ent_col;
+  float* ent_val;
+  unsigned long long* pool_top; /* zeroed before launch */
+  uint64_t pool_cap;            /* capacity of ent_col/ent_val in entries */
+  uint64_t* pair_off;
+  uint32_t* pair_nnz;
+  float* sim;                   /* similarity score per task (dafs.cpp:763) */
+  int* status;                  /* zeroed; set to DAFS_HIP_EOVERFLOW when the pool is exhausted */
+  dafs_pairhmm3_model model;
+} dafs_pairhmm3_args;
+
+int dafs_hipk_pairhmm_plan(uint32_t ntasks, uint32_t max_len1, uint32_t max_len2, dafs_pairhmm_plan* plan);
+int dafs_hipk_pairhmm3_launch(const dafs_pairhmm3_args* args, const dafs_pairhmm_plan* plan, void* hip_stream);
+/* Host-side model tables: log of the ProbCons defaults, computed with logf like the reference
+ * constructor (ProbabilisticModel.h:55-88). */
+void dafs_hip_pairhmm3_default_model(dafs_pairhmm3_model* m);
+/* residue byte -> class code (wrapper.cpp:157-170: case-insensitive "ACGUTN", else 'other') */
+uint8_t dafs_hip_residue_code(char c);
+
+/* ------------------------------------------------------------------------------------------
+ * L1: batch alignment-posterior plugin.
+ * Replaces Align::Model::calculate(const vector<Fasta>&, vector<vector<MP>>&)
+ * (src/align.cpp:35-52) for -a ProbCons, plus the transposes (src/dafs.cpp:1797-1799) and
+ * sim_ (src/dafs.cpp:1813-1819), for the pair-index shard [pair_begin, pair_end) of the
+ * row-major (i<j) pair enumeration (pair_end = 0 means all pairs).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dafs_hip_ctx dafs_hip_ctx;
+int dafs_hip_create(int device, dafs_hip_ctx** ctx);
+void dafs_hip_destroy(dafs_hip_ctx* ctx);
+
+int dafs_hip_set_sequences(dafs_hip_ctx* ctx, uint32_t nseq, const char* const* seqs, const uint32_t* lens);
+int dafs_hip_align_posteriors(dafs_hip_ctx* ctx, int model, float th, uint64_t pair_begin, uint64_t pair_end);
+/* sizes of the result held in the context */
+int dafs_hip_align_result_size(dafs_hip_ctx* ctx, uint64_t* npairs, uint64_t* total_nnz, uint64_t* total_rowptr);
+/* Copy out, pairs in shard order p = pair_begin..: pair_x/pair_y[npairs]; sim[npairs];
+ * nnz[npairs]; rowptr: for each pair len_x+1 entries (relative) then len_y+1 (transposed);
+ * col/val: for each pair nnz entries of mp[x][y] then nnz of mp[y][x]. Any pointer may be NULL. */
+int dafs_hip_align_fetch(dafs_hip_ctx* ctx, uint32_t* pair_x, uint32_t* pair_y, float* sim, uint32_t* nnz,
+                         uint32_t* rowptr, uint32_t* col, float* val);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
