@@ -67,6 +67,14 @@ _align_posteriors = _sig("dafs_hip_align_posteriors", C.c_int, [C.c_void_p, C.c_
 _align_result_size = _sig("dafs_hip_align_result_size", C.c_int,
                           [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
 _align_fetch = _sig("dafs_hip_align_fetch", C.c_int, [C.c_void_p] + [C.c_void_p] * 7)
+_mp_result_size = _sig("dafs_hip_mp_result_size", C.c_int,
+                      [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
+_mp_fetch = _sig("dafs_hip_mp_fetch", C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6)
+_get_sim = _sig("dafs_hip_get_sim", C.c_int, [C.c_void_p, C.c_void_p])
+_set_bp = _sig("dafs_hip_set_bp", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
+_bp_result_size = _sig("dafs_hip_bp_result_size", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
+_bp_fetch = _sig("dafs_hip_bp_fetch", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
+_consistency = _sig("dafs_hip_consistency", C.c_int, [C.c_void_p, C.c_float, C.c_float])
 pairhmm_plan = _sig("dafs_hipk_pairhmm_plan", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PairhmmPlan)])
 pairhmm3_launch = _sig("dafs_hipk_pairhmm3_launch", C.c_int, [C.POINTER(Pairhmm3Args), C.POINTER(PairhmmPlan), C.c_void_p])
 pairhmm3_default_model = _sig("dafs_hip_pairhmm3_default_model", None, [C.POINTER(Pairhmm3Model)])
@@ -150,3 +158,47 @@ class Context:
         check(_align_fetch(self._h, px.ctypes.data, py.ctypes.data, sim.ctypes.data, cnt.ctypes.data,
                            rowptr.ctypes.data, col.ctypes.data, val.ctypes.data))
         return PairPosteriors(px, py, sim, cnt, rowptr, col, val, self._lens)
+
+    def mp(self, relaxed):
+        """the matching-probability store (0: model output, 1: after consistency) as PairPosteriors"""
+        npairs, nnz, nrp = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(_mp_result_size(self._h, relaxed, C.byref(npairs), C.byref(nnz), C.byref(nrp)))
+        n = npairs.value
+        px = np.zeros(n, np.uint32); py = np.zeros(n, np.uint32); cnt = np.zeros(n, np.uint32)
+        rowptr = np.zeros(nrp.value, np.uint32)
+        col = np.zeros(2 * nnz.value, np.uint32); val = np.zeros(2 * nnz.value, np.float32)
+        check(_mp_fetch(self._h, relaxed, px.ctypes.data, py.ctypes.data, cnt.ctypes.data,
+                        rowptr.ctypes.data, col.ctypes.data, val.ctypes.data))
+        return PairPosteriors(px, py, None, cnt, rowptr, col, val, self._lens)
+
+    def sim(self):
+        n = len(self._lens)
+        out = np.zeros((n, n), np.float32)
+        check(_get_sim(self._h, out.ctypes.data))
+        return out
+
+    def set_bp(self, rows):
+        """rows: per sequence (rowptr[len+1], col, val)"""
+        rp = np.concatenate([np.asarray(r[0], np.uint32) for r in rows])
+        col = np.concatenate([np.asarray(r[1], np.uint32) for r in rows]) if rows else np.zeros(0, np.uint32)
+        val = np.concatenate([np.asarray(r[2], np.float32) for r in rows]) if rows else np.zeros(0, np.float32)
+        rp = np.ascontiguousarray(rp); col = np.ascontiguousarray(col); val = np.ascontiguousarray(val)
+        check(_set_bp(self._h, rp.ctypes.data, col.ctypes.data if len(col) else None, val.ctypes.data if len(val) else None))
+
+    def bp(self, relaxed):
+        """per sequence (rowptr, col, val)"""
+        nnz, nrp = C.c_uint64(), C.c_uint64()
+        check(_bp_result_size(self._h, relaxed, C.byref(nnz), C.byref(nrp)))
+        rp = np.zeros(nrp.value, np.uint32); col = np.zeros(nnz.value, np.uint32); val = np.zeros(nnz.value, np.float32)
+        check(_bp_fetch(self._h, relaxed, rp.ctypes.data, col.ctypes.data, val.ctypes.data))
+        out, r0, e0 = [], 0, 0
+        for L in self._lens:
+            r = rp[r0:r0 + int(L) + 1]
+            n = int(r[-1])
+            out.append((r, col[e0:e0 + n], val[e0:e0 + n]))
+            r0 += int(L) + 1
+            e0 += n
+        return out
+
+    def consistency(self, w_pct_a=0.25, w_pct_s=0.25):
+        check(_consistency(self._h, w_pct_a, w_pct_s))

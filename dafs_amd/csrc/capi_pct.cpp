@@ -1,0 +1,168 @@
+// dafs_amd/csrc/capi_pct.cpp -- L1: base-pairing store upload/fetch and the two probabilistic
+// consistency transforms (reference src/dafs.cpp:258-375, called at :1822-1827).
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#include "../../include/dafs_hip.h"
+#include "ctx.h"
+#include "hip_util.h"
+#include "pct.h"
+
+using namespace dafs;
+
+// AUXFold equivalent (reference src/fold.cpp:230-278): base-pairing probabilities supplied by
+// the caller.  rowptr: per sequence len+1 entries (relative to that sequence's first entry),
+// concatenated; col/val: all sequences' entries concatenated, rows ascending, j > i.
+extern "C" int dafs_hip_set_bp(dafs_hip_ctx* c, const uint32_t* rowptr, const uint32_t* col, const float* val) {
+  if (!c || c->len.empty() || !rowptr) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  const uint32_t n = (uint32_t)c->len.size();
+  bp_store& st = c->bp[0];
+  st.valid = false;
+  c->bp[1].valid = false;
+  c->cur_bp = 0;
+  std::vector<uint64_t> bp_off(n + 1, 0);
+  std::vector<uint32_t> nnz(n);
+  for (uint32_t x = 0; x < n; ++x) {
+    nnz[x] = rowptr[c->seq_rp_off[x] + c->len[x]];
+    bp_off[x + 1] = bp_off[x] + nnz[x];
+  }
+  const uint64_t total = bp_off[n];
+  if (total && (!col || !val)) return DAFS_HIP_EINVAL;
+  int rc;
+  if ((rc = st.rowptr.upload(rowptr, c->seq_rp_off[n], c->stream))) return rc;
+  if ((rc = st.col.upload(col, total, c->stream))) return rc;
+  if ((rc = st.val.upload(val, total, c->stream))) return rc;
+  if ((rc = st.nnz.upload(nnz.data(), n, c->stream))) return rc;
+  if ((rc = st.bp_off.upload(bp_off.data(), n + 1, c->stream))) return rc;
+  if ((rc = st.rp_off.upload(c->seq_rp_off.data(), n + 1, c->stream))) return rc;
+  st.total_nnz = total;
+  st.valid = true;
+  return DAFS_HIP_OK;
+}
+
+extern "C" int dafs_hip_bp_result_size(dafs_hip_ctx* c, int relaxed, uint64_t* total_nnz, uint64_t* total_rowptr) {
+  if (!c || relaxed < 0 || relaxed > 1 || !c->bp[relaxed].valid) return DAFS_HIP_EINVAL;
+  if (total_nnz) *total_nnz = c->bp[relaxed].total_nnz;
+  if (total_rowptr) *total_rowptr = c->seq_rp_off.back();
+  return DAFS_HIP_OK;
+}
+
+// Same layout as dafs_hip_set_bp, sequences in input order.
+extern "C" int dafs_hip_bp_fetch(dafs_hip_ctx* c, int relaxed, uint32_t* rowptr, uint32_t* col, float* val) {
+  if (!c || relaxed < 0 || relaxed > 1 || !c->bp[relaxed].valid) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  const bp_store& st = c->bp[relaxed];
+  const uint32_t n = (uint32_t)c->len.size();
+  int rc;
+  if (rowptr && (rc = st.rowptr.download(rowptr, c->seq_rp_off[n]))) return rc;
+  if (!col && !val) return DAFS_HIP_OK;
+  std::vector<uint64_t> off(n + 1);
+  std::vector<uint32_t> nnz(n);
+  if ((rc = st.bp_off.download(off.data(), n + 1))) return rc;
+  if ((rc = st.nnz.download(nnz.data(), n))) return rc;
+  std::vector<uint32_t> h_col(st.total_nnz);
+  std::vector<float> h_val(st.total_nnz);
+  if ((rc = st.col.download(h_col.data(), st.total_nnz))) return rc;
+  if ((rc = st.val.download(h_val.data(), st.total_nnz))) return rc;
+  uint64_t w = 0;
+  for (uint32_t x = 0; x < n; ++x) {  // the relaxed pool is bump-allocated: reorder by sequence
+    if (col) memcpy(col + w, h_col.data() + off[x], nnz[x] * sizeof(uint32_t));
+    if (val) memcpy(val + w, h_val.data() + off[x], nnz[x] * sizeof(float));
+    w += nnz[x];
+  }
+  return DAFS_HIP_OK;
+}
+
+// relax_basepairing_probability then relax_matching_probability, both from the un-relaxed
+// stores (dafs.cpp:1822-1827).  A weight of 0 skips that transform, as the reference does.
+extern "C" int dafs_hip_consistency(dafs_hip_ctx* c, float w_pct_a, float w_pct_s) {
+  if (!c || c->len.empty()) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  const uint32_t n = (uint32_t)c->len.size();
+  const uint64_t all = (uint64_t)n * (n - 1) / 2;
+  mp_store& raw = c->mp[0];
+  if (!raw.valid || raw.n_tasks != all || c->sim.empty()) return DAFS_HIP_EINVAL;
+  const uint32_t max_len = c->max_len();
+  const mp_store_dev mpv = raw.view(c->d_len.ptr, n);
+  int rc;
+  if ((rc = c->counters.reserve(4))) return rc;
+
+  c->cur_bp = 0;
+  if (w_pct_s != 0.0f) {
+    if (!c->bp[0].valid) return DAFS_HIP_EINVAL;
+    bp_store& in = c->bp[0];
+    bp_store& out = c->bp[1];
+    out.valid = false;
+    if ((rc = out.rowptr.reserve(c->seq_rp_off[n]))) return rc;
+    if ((rc = out.nnz.reserve(n))) return rc;
+    if ((rc = out.bp_off.reserve(n + 1))) return rc;
+    if ((rc = out.rp_off.upload(c->seq_rp_off.data(), n + 1, c->stream))) return rc;
+    uint64_t cap = std::max<uint64_t>(4 * in.total_nnz + 1024, 16ull * c->off[n]);
+    for (int attempt = 0;; ++attempt) {
+      if ((rc = out.col.reserve(cap))) return rc;
+      if ((rc = out.val.reserve(cap))) return rc;
+      if (hip_check(hipMemsetAsync(c->counters.ptr, 0, 4 * sizeof(unsigned long long), c->stream))) return DAFS_HIP_ELAUNCH;
+      pct_bp_args a;
+      memset(&a, 0, sizeof a);
+      a.mp = mpv; a.bp = in.view(); a.sim = c->d_sim.ptr; a.w_pct = w_pct_s;
+      a.out_rowptr = out.rowptr.ptr; a.out_col = out.col.ptr; a.out_val = out.val.ptr;
+      a.pool_top = c->counters.ptr; a.pool_cap = cap; a.out_off = out.bp_off.ptr; a.out_nnz = out.nnz.ptr;
+      a.status = (int*)(c->counters.ptr + 2);
+      if ((rc = pct_bp_launch(a, max_len, c->stream))) return rc;
+      unsigned long long h[4];
+      if (hip_check(hipMemcpyAsync(h, c->counters.ptr, sizeof h, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+      if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
+      const int status = (int)(h[2] & 0xffffffffu);
+      if (status == 0) { out.total_nnz = h[0]; out.valid = true; break; }
+      if (status != DAFS_HIP_EOVERFLOW || attempt >= 4) return status;
+      cap = std::max<uint64_t>(h[0], cap * 2);
+    }
+    c->cur_bp = 1;
+  }
+
+  c->cur_mp = 0;
+  if (w_pct_a != 0.0f) {
+    mp_store& out = c->mp[1];
+    out.valid = false;
+    out.n_tasks = all;
+    out.pair_x = raw.pair_x;
+    out.pair_y = raw.pair_y;
+    out.rp_by_pair = raw.rp_by_pair;
+    out.rp_total = raw.rp_total;
+    out.task_of_pair.resize(all);
+    for (uint64_t p = 0; p < all; ++p) out.task_of_pair[p] = (uint32_t)p;
+    if ((rc = out.d_task_of_pair.upload(out.task_of_pair.data(), all, c->stream))) return rc;
+    if ((rc = out.rp_off.upload(out.rp_by_pair.data(), all, c->stream))) return rc;
+    if ((rc = out.rowptr_pool.reserve(out.rp_total))) return rc;
+    if ((rc = out.pair_off.reserve(all))) return rc;
+    if ((rc = out.pair_nnz.reserve(all))) return rc;
+    if ((rc = c->d_pair_x.upload(raw.pair_x.data(), all, c->stream))) return rc;
+    if ((rc = c->d_pair_y.upload(raw.pair_y.data(), all, c->stream))) return rc;
+    uint64_t cap = std::max<uint64_t>(raw.pool_used * 2 + 1024, out.pool_cap_hint);
+    for (int attempt = 0;; ++attempt) {
+      if ((rc = out.col.reserve(cap))) return rc;
+      if ((rc = out.val.reserve(cap))) return rc;
+      if (hip_check(hipMemsetAsync(c->counters.ptr, 0, 4 * sizeof(unsigned long long), c->stream))) return DAFS_HIP_ELAUNCH;
+      pct_match_args a;
+      memset(&a, 0, sizeof a);
+      a.in = mpv; a.sim = c->d_sim.ptr; a.pair_x = c->d_pair_x.ptr; a.pair_y = c->d_pair_y.ptr;
+      a.npairs = (uint32_t)all; a.w_pct = w_pct_a;
+      a.rp_off = out.rp_off.ptr; a.rowptr_pool = out.rowptr_pool.ptr; a.col = out.col.ptr; a.val = out.val.ptr;
+      a.pool_top = c->counters.ptr; a.pool_cap = cap; a.pair_off = out.pair_off.ptr; a.pair_nnz = out.pair_nnz.ptr;
+      a.status = (int*)(c->counters.ptr + 2);
+      if ((rc = pct_match_launch(a, max_len, c->stream))) return rc;
+      unsigned long long h[4];
+      if (hip_check(hipMemcpyAsync(h, c->counters.ptr, sizeof h, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+      if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
+      const int status = (int)(h[2] & 0xffffffffu);
+      if (status == 0) { out.pool_used = h[0]; out.pool_cap_hint = cap; out.valid = true; break; }
+      if (status != DAFS_HIP_EOVERFLOW || attempt >= 4) return status;
+      cap = std::max<uint64_t>(h[0], cap * 2);
+    }
+    c->cur_mp = 1;
+  }
+  return DAFS_HIP_OK;
+}

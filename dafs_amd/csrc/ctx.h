@@ -1,5 +1,5 @@
 // dafs_amd/csrc/ctx.h -- the context object behind the L1 entry points: device buffers that stay
-// resident between calls (sequence codes, the sparse posterior pools, similarity scores).
+// resident between calls (sequence codes, the sparse posterior stores, similarity scores).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -8,6 +8,7 @@
 
 #include "../../include/dafs_hip.h"
 #include "hip_util.h"
+#include "sparse_view.h"
 
 namespace dafs {
 
@@ -17,7 +18,7 @@ struct dev_buf {
   T* ptr = nullptr;
   size_t cap = 0;
   int reserve(size_t n) {
-    if (n <= cap) return DAFS_HIP_OK;
+    if (n <= cap && ptr) return DAFS_HIP_OK;
     if (ptr) (void)hipFree(ptr);
     ptr = nullptr;
     cap = 0;
@@ -33,11 +34,52 @@ struct dev_buf {
     if (hip_check(hipStreamSynchronize(st))) return DAFS_HIP_ELAUNCH;  // host vector may die after return
     return DAFS_HIP_OK;
   }
+  int download(T* host, size_t n) const {
+    if (n && hip_check(hipMemcpy(host, ptr, n * sizeof(T), hipMemcpyDeviceToHost))) return DAFS_HIP_ELAUNCH;
+    return DAFS_HIP_OK;
+  }
   void release() {
     if (ptr) (void)hipFree(ptr);
     ptr = nullptr;
     cap = 0;
   }
+};
+
+// Matching-probability store: per task the rows of mp[x][y] followed by those of mp[y][x].
+struct mp_store {
+  bool valid = false;
+  uint64_t n_tasks = 0, rp_total = 0, pool_used = 0, pool_cap_hint = 0;
+  std::vector<uint32_t> pair_x, pair_y;   // per pair of the shard, shard order
+  std::vector<uint32_t> task_of_pair;     // shard-order pair -> task (processing order)
+  std::vector<uint64_t> rp_by_pair;
+  dev_buf<uint32_t> rowptr_pool, col, pair_nnz, d_task_of_pair;
+  dev_buf<float> val;
+  dev_buf<uint64_t> pair_off, rp_off;
+  mp_store_dev view(const uint32_t* d_len, uint32_t nseq) const {
+    mp_store_dev v;
+    v.rowptr_pool = rowptr_pool.ptr; v.col = col.ptr; v.val = val.ptr; v.pair_off = pair_off.ptr;
+    v.pair_nnz = pair_nnz.ptr; v.rp_off = rp_off.ptr; v.task_of_pair = d_task_of_pair.ptr; v.len = d_len; v.nseq = nseq;
+    return v;
+  }
+  void release() {
+    rowptr_pool.release(); col.release(); pair_nnz.release(); d_task_of_pair.release(); val.release();
+    pair_off.release(); rp_off.release(); valid = false;
+  }
+};
+
+// Base-pairing store: per sequence x the rows i -> (j > i, p).
+struct bp_store {
+  bool valid = false;
+  uint64_t total_nnz = 0;
+  dev_buf<uint32_t> rowptr, col, nnz;
+  dev_buf<float> val;
+  dev_buf<uint64_t> rp_off, bp_off;
+  bp_store_dev view() const {
+    bp_store_dev v;
+    v.rowptr = rowptr.ptr; v.col = col.ptr; v.val = val.ptr; v.rp_off = rp_off.ptr; v.bp_off = bp_off.ptr;
+    return v;
+  }
+  void release() { rowptr.release(); col.release(); nnz.release(); val.release(); rp_off.release(); bp_off.release(); valid = false; }
 };
 
 }  // namespace dafs
@@ -48,22 +90,28 @@ struct dafs_hip_ctx {
   // sequences
   std::string seq;
   std::vector<uint32_t> len, off;
+  std::vector<uint64_t> seq_rp_off;  // per sequence: first row pointer in a per-sequence CSR (sum of len+1)
   dafs::dev_buf<uint8_t> codes;
-  // alignment-posterior shard
-  bool align_valid = false;
-  uint64_t n_tasks = 0, rp_total = 0, pool_used = 0, pool_cap_hint = 0;
-  std::vector<uint32_t> pair_x, pair_y, task_order;
-  std::vector<uint64_t> rp_by_pair;
+  dafs::dev_buf<uint32_t> d_len;
+  dafs::dev_buf<uint64_t> d_seq_rp_off;
+  // pair-HMM launch workspace
   dafs_pairhmm_plan plan{};
   dafs::dev_buf<dafs_pair_task> tasks;
-  dafs::dev_buf<uint64_t> rp_off, pair_off;
-  dafs::dev_buf<float> scratch, ent_val, sim;
-  dafs::dev_buf<uint32_t> rowptr_pool, ent_col, pair_nnz;
+  dafs::dev_buf<float> scratch, task_sim;
   dafs::dev_buf<unsigned long long> counters;
+  // stores: [0] as computed by the models, [1] after the consistency transforms
+  dafs::mp_store mp[2];
+  dafs::bp_store bp[2];
+  int cur_mp = 0, cur_bp = 0;
+  // similarity matrix (host copy + device dense N*N)
+  std::vector<float> sim;
+  dafs::dev_buf<float> d_sim;
+  dafs::dev_buf<uint32_t> d_pair_x, d_pair_y;
+  uint32_t max_len() const { uint32_t m = 0; for (uint32_t l : len) m = l > m ? l : m; return m; }
 
   void free_all() {
-    codes.release(); tasks.release(); rp_off.release(); pair_off.release(); scratch.release();
-    ent_val.release(); sim.release(); rowptr_pool.release(); ent_col.release(); pair_nnz.release();
-    counters.release();
+    codes.release(); d_len.release(); d_seq_rp_off.release(); tasks.release(); scratch.release(); task_sim.release();
+    counters.release(); d_sim.release(); d_pair_x.release(); d_pair_y.release();
+    for (int k = 0; k < 2; ++k) { mp[k].release(); bp[k].release(); }
   }
 };

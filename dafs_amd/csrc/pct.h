@@ -1,0 +1,49 @@
+// dafs_amd/csrc/pct.h -- launch arguments of the consistency-transform kernels (pct.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sparse_view.h"
+
+namespace dafs {
+
+struct pct_match_args {
+  mp_store_dev in;        // un-relaxed matching probabilities
+  const float* sim;       // N*N similarity matrix (diagonal 1)
+  const uint32_t* pair_x; // output pair p -> (x, y), row-major x<y
+  const uint32_t* pair_y;
+  uint32_t npairs;
+  float w_pct;            // reference -p (w_pct_a_)
+  // output store; task == row-major pair id
+  const uint64_t* rp_off;
+  uint32_t* rowptr_pool;
+  uint32_t* col;
+  float* val;
+  unsigned long long* pool_top;
+  uint64_t pool_cap;
+  uint64_t* pair_off;
+  uint32_t* pair_nnz;
+  int* status;
+  uint32_t max_len, tile_cells;  // filled by the launcher
+};
+
+struct pct_bp_args {
+  mp_store_dev mp;    // un-relaxed matching probabilities
+  bp_store_dev bp;    // un-relaxed base-pairing probabilities
+  const float* sim;
+  float w_pct;        // reference -q (w_pct_s_)
+  // output: same row-pointer layout as the input store (bp.rp_off)
+  uint32_t* out_rowptr;
+  uint32_t* out_col;
+  float* out_val;
+  unsigned long long* pool_top;
+  uint64_t pool_cap;
+  uint64_t* out_off;
+  uint32_t* out_nnz;
+  int* status;
+  uint32_t max_len, tile_cells;
+};
+
+int pct_match_launch(pct_match_args a, uint32_t max_len, hipStream_t st);
+int pct_bp_launch(pct_bp_args a, uint32_t max_len, hipStream_t st);
+
+}  // namespace dafs

@@ -131,6 +131,32 @@ int dafs_hip_align_result_size(dafs_hip_ctx* ctx, uint64_t* npairs, uint64_t* to
 int dafs_hip_align_fetch(dafs_hip_ctx* ctx, uint32_t* pair_x, uint32_t* pair_y, float* sim, uint32_t* nnz,
                          uint32_t* rowptr, uint32_t* col, float* val);
 
+/* Generic access to the matching-probability stores: relaxed = 0 as computed by the alignment
+ * model, 1 after dafs_hip_consistency (layout as dafs_hip_align_fetch). */
+int dafs_hip_mp_result_size(dafs_hip_ctx* ctx, int relaxed, uint64_t* npairs, uint64_t* total_nnz, uint64_t* total_rowptr);
+int dafs_hip_mp_fetch(dafs_hip_ctx* ctx, int relaxed, uint32_t* pair_x, uint32_t* pair_y, uint32_t* nnz,
+                      uint32_t* rowptr, uint32_t* col, float* val);
+/* sim_ (src/dafs.cpp:1813-1819): N*N floats, unit diagonal; needs a full-pair-set align_posteriors. */
+int dafs_hip_get_sim(dafs_hip_ctx* ctx, float* sim);
+
+/* ------------------------------------------------------------------------------------------
+ * L1: base-pairing probabilities.
+ * dafs_hip_set_bp replaces AUXFold::calculate (src/fold.cpp:261-278, --fold-aux): the caller
+ * supplies BP rows.  rowptr: per sequence len+1 entries relative to that sequence's first entry,
+ * concatenated in input order; col/val: entries (j > i, p) of all sequences concatenated.
+ * ---------------------------------------------------------------------------------------- */
+int dafs_hip_set_bp(dafs_hip_ctx* ctx, const uint32_t* rowptr, const uint32_t* col, const float* val);
+int dafs_hip_bp_result_size(dafs_hip_ctx* ctx, int relaxed, uint64_t* total_nnz, uint64_t* total_rowptr);
+int dafs_hip_bp_fetch(dafs_hip_ctx* ctx, int relaxed, uint32_t* rowptr, uint32_t* col, float* val);
+
+/* ------------------------------------------------------------------------------------------
+ * L1: probabilistic consistency transforms.
+ * Replaces DAFS::relax_basepairing_probability (src/dafs.cpp:326-375) and
+ * DAFS::relax_matching_probability (src/dafs.cpp:258-324) as called from DAFS::run
+ * (src/dafs.cpp:1822-1827): both read the un-relaxed stores; weight 0 skips a transform.
+ * ---------------------------------------------------------------------------------------- */
+int dafs_hip_consistency(dafs_hip_ctx* ctx, float w_pct_a, float w_pct_s);
+
 #ifdef __cplusplus
 }
 #endif
