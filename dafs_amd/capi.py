@@ -75,6 +75,35 @@ _set_bp = _sig("dafs_hip_set_bp", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, 
 _bp_result_size = _sig("dafs_hip_bp_result_size", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
 _bp_fetch = _sig("dafs_hip_bp_fetch", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
 _consistency = _sig("dafs_hip_consistency", C.c_int, [C.c_void_p, C.c_float, C.c_float])
+
+
+class NodeInput(C.Structure):
+    _fields_ = [("n1", C.c_uint32), ("n2", C.c_uint32), ("len1", C.c_uint32), ("len2", C.c_uint32),
+                ("seq1", C.c_void_p), ("seq2", C.c_void_p), ("mask1", C.c_void_p), ("mask2", C.c_void_p)]
+
+
+class NodeOutput(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("score", C.c_float),
+                ("ncbp", C.c_uint32), ("iterations", C.c_uint32), ("violated", C.c_uint32)]
+
+
+class DDParams(C.Structure):
+    _fields_ = [("w", C.c_float), ("eta0", C.c_float), ("th_a", C.c_float), ("th_s", C.c_float),
+                ("t_max", C.c_uint32), ("force_iters", C.c_int)]
+
+
+_nussinov_decode = _sig("dafs_hip_nussinov_decode", C.c_int,
+                        [C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)])
+_nw_envelope = _sig("dafs_hip_nw_envelope", C.c_int, [C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p])
+_nw_decode = _sig("dafs_hip_nw_decode", C.c_int,
+                  [C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)])
+_make_brackets = _sig("dafs_hip_make_brackets", None, [C.c_uint32, C.c_void_p, C.c_char_p])
+_dd_default_params = _sig("dafs_hip_dd_default_params", None, [C.POINTER(DDParams)])
+_solve_nodes = _sig("dafs_hip_solve_nodes", C.c_int,
+                    [C.c_void_p, C.c_uint32, C.POINTER(NodeInput), C.POINTER(DDParams), C.POINTER(NodeOutput)])
+_consensus_structure = _sig("dafs_hip_consensus_structure", C.c_int,
+                            [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                             C.POINTER(C.c_float), C.c_void_p])
 pairhmm_plan = _sig("dafs_hipk_pairhmm_plan", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PairhmmPlan)])
 pairhmm3_launch = _sig("dafs_hipk_pairhmm3_launch", C.c_int, [C.POINTER(Pairhmm3Args), C.POINTER(PairhmmPlan), C.c_void_p])
 pairhmm3_default_model = _sig("dafs_hip_pairhmm3_default_model", None, [C.POINTER(Pairhmm3Model)])
@@ -202,3 +231,78 @@ class Context:
 
     def consistency(self, w_pct_a=0.25, w_pct_s=0.25):
         check(_consistency(self._h, w_pct_a, w_pct_s))
+
+    # --- decoder plugins ---
+    def nussinov(self, p, q, th, w=0.0):
+        p = np.ascontiguousarray(p, np.float32)
+        L = p.shape[0]
+        qq = None if q is None else np.ascontiguousarray(q, np.float32)
+        ss = np.zeros(L, np.uint32)
+        score = C.c_float()
+        check(_nussinov_decode(self._h, th, w, L, p.ctypes.data, None if qq is None else qq.ctypes.data,
+                               ss.ctypes.data, C.byref(score)))
+        return np.float32(score.value), ss
+
+    def nw_envelope(self, p, th):
+        p = np.ascontiguousarray(p, np.float32)
+        env = np.zeros(2 * (p.shape[0] + 1), np.uint32)
+        check(_nw_envelope(self._h, th, p.shape[0], p.shape[1], p.ctypes.data, env.ctypes.data))
+        return env
+
+    def nw(self, p, q, th, env=None):
+        p = np.ascontiguousarray(p, np.float32)
+        if env is None:
+            env = self.nw_envelope(p, th)
+        qq = None if q is None else np.ascontiguousarray(q, np.float32)
+        al = np.zeros(p.shape[0], np.uint32)
+        score = C.c_float()
+        check(_nw_decode(self._h, th, p.shape[0], p.shape[1], p.ctypes.data, None if qq is None else qq.ctypes.data,
+                         env.ctypes.data, al.ctypes.data, C.byref(score)))
+        return np.float32(score.value), al
+
+    # --- fused node solver ---
+    def solve_nodes(self, nodes, prm=None):
+        """nodes: list of (seq1, mask1, seq2, mask2) with seq* uint32 arrays and mask* uint8 [n, len].
+        Returns list of dicts x, y, z, score, ncbp, iterations, violated."""
+        if prm is None:
+            prm = dd_params()
+        n = len(nodes)
+        ins = (NodeInput * n)()
+        outs = (NodeOutput * n)()
+        keep = []
+        for b, (s1, m1, s2, m2) in enumerate(nodes):
+            s1 = np.ascontiguousarray(s1, np.uint32); s2 = np.ascontiguousarray(s2, np.uint32)
+            m1 = np.ascontiguousarray(m1, np.uint8); m2 = np.ascontiguousarray(m2, np.uint8)
+            x = np.zeros(m1.shape[1], np.uint32); y = np.zeros(m2.shape[1], np.uint32); z = np.zeros(m1.shape[1], np.uint32)
+            keep.append((s1, s2, m1, m2, x, y, z))
+            ins[b].n1, ins[b].n2, ins[b].len1, ins[b].len2 = m1.shape[0], m2.shape[0], m1.shape[1], m2.shape[1]
+            ins[b].seq1, ins[b].seq2, ins[b].mask1, ins[b].mask2 = s1.ctypes.data, s2.ctypes.data, m1.ctypes.data, m2.ctypes.data
+            outs[b].x, outs[b].y, outs[b].z = x.ctypes.data, y.ctypes.data, z.ctypes.data
+        check(_solve_nodes(self._h, n, ins, C.byref(prm), outs))
+        return [dict(x=k[4], y=k[5], z=k[6], score=np.float32(outs[b].score), ncbp=outs[b].ncbp,
+                     iterations=outs[b].iterations, violated=outs[b].violated) for b, k in enumerate(keep)]
+
+    def consensus_structure(self, seq, mask, th, want_p=False):
+        seq = np.ascontiguousarray(seq, np.uint32); mask = np.ascontiguousarray(mask, np.uint8)
+        n, L = mask.shape
+        ss = np.zeros(L, np.uint32)
+        score = C.c_float()
+        p = np.zeros((L, L), np.float32) if want_p else None
+        check(_consensus_structure(self._h, n, L, seq.ctypes.data, mask.ctypes.data, th, ss.ctypes.data, C.byref(score),
+                                   None if p is None else p.ctypes.data))
+        return np.float32(score.value), ss, p
+
+
+def dd_params(**kw):
+    p = DDParams()
+    _dd_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def make_brackets(ss):
+    ss = np.ascontiguousarray(ss, np.uint32)
+    buf = C.create_string_buffer(len(ss) + 1)
+    _make_brackets(len(ss), ss.ctypes.data, buf)
+    return buf.value.decode()

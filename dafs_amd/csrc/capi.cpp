@@ -142,3 +142,11 @@ extern "C" int dafs_hip_set_sequences(dafs_hip_ctx* c, uint32_t nseq, const char
   c->sim.clear();
   return DAFS_HIP_OK;
 }
+
+// make_brackets, reference src/nussinov.cpp:401-413 with brackets[0] = "()" (src/fold.cpp:57-58)
+extern "C" void dafs_hip_make_brackets(uint32_t L, const uint32_t* ss, char* str) {
+  memset(str, '.', L);
+  str[L] = 0;
+  for (uint32_t i = 0; i != L; ++i)
+    if (ss[i] != DAFS_HIP_NONE) { str[i] = '('; str[ss[i]] = ')'; }
+}

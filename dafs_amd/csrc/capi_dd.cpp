@@ -1,0 +1,340 @@
+// dafs_amd/csrc/capi_dd.cpp -- L1: the decoder plugins (Fold::Decoder / Align::Decoder,
+// reference src/fold.h:47-60, src/align.h:57-65) and the fused per-node solver
+// (DAFS::align_alignments + DAFS::solve_by_dd, reference src/dafs.cpp:896-981, 1006-1295).
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#include "../../include/dafs_hip.h"
+#include "ctx.h"
+#include "dd.h"
+#include "hip_util.h"
+
+using namespace dafs;
+
+namespace {
+
+// bump allocator over one device buffer (256-byte aligned pieces)
+struct carver {
+  uint8_t* base = nullptr;
+  size_t used = 0;
+  template <class T>
+  T* take(size_t n) {
+    used = (used + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + used) : nullptr;
+    used += n * sizeof(T);
+    return p;
+  }
+};
+
+struct region { size_t off, bytes; int value; };
+
+void carve_nuss(carver& cv, uint32_t L, nuss_ws& w) {
+  const size_t LL = (size_t)L * L;
+  w.dp = cv.take<float>(LL + 1);
+  w.tr = cv.take<uint32_t>(LL + 1);
+  w.ck = cv.take<uint32_t>(LL + 2 * (size_t)L + 16);  // doubles as the traceback stack
+  w.cv = cv.take<float>(LL + 1);
+  w.cc = cv.take<uint32_t>((size_t)L + 1);
+}
+
+}  // namespace
+
+extern "C" int dafs_hip_nussinov_decode(dafs_hip_ctx* c, float th, float w, uint32_t L, const float* p, const float* q,
+                                        uint32_t* ss, float* score) {
+  if (!c || !p || !ss || L == 0) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  const size_t LL = (size_t)L * L;
+  carver cv;
+  for (int pass = 0; pass < 2; ++pass) {
+    cv.used = 0;
+    float* d_p = cv.take<float>(LL);
+    float* d_q = q ? cv.take<float>(LL) : nullptr;
+    nuss_ws ws;
+    carve_nuss(cv, L, ws);
+    uint32_t* d_ss = cv.take<uint32_t>(L);
+    float* d_score = cv.take<float>(1);
+    if (pass == 0) {
+      int rc = c->work.reserve(cv.used + 256);
+      if (rc) return rc;
+      cv.base = c->work.ptr;
+      continue;
+    }
+    if (hip_check(hipMemcpyAsync(d_p, p, LL * 4, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
+    if (q && hip_check(hipMemcpyAsync(d_q, q, LL * 4, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
+    int rc = nussinov_launch(L, d_p, d_q, w, th, ws, d_ss, d_score, c->stream);
+    if (rc) return rc;
+    if (hip_check(hipMemcpyAsync(ss, d_ss, (size_t)L * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+    float s = 0;
+    if (hip_check(hipMemcpyAsync(&s, d_score, 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+    if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
+    if (score) *score = s;
+  }
+  return DAFS_HIP_OK;
+}
+
+static int nw_common(dafs_hip_ctx* c, float th, uint32_t L1, uint32_t L2, const float* p, const float* q, uint32_t* env,
+                     int compute_env, int decode, uint32_t* al, float* score) {
+  if (!c || !p || !env || L1 == 0 || L2 == 0) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  const size_t C = (size_t)L1 * L2, T = (size_t)(L1 + 1) * (L2 + 1);
+  carver cv;
+  for (int pass = 0; pass < 2; ++pass) {
+    cv.used = 0;
+    float* d_p = cv.take<float>(C);
+    float* d_q = q ? cv.take<float>(C) : nullptr;
+    float* d_dp = cv.take<float>(T + L1 + 2);
+    uint8_t* d_tr = cv.take<uint8_t>(T);
+    uint32_t* d_env = cv.take<uint32_t>(2 * ((size_t)L1 + 1));
+    uint32_t* d_al = cv.take<uint32_t>((size_t)L1 + 2);
+    float* d_score = cv.take<float>(1);
+    if (pass == 0) {
+      int rc = c->work.reserve(cv.used + 256);
+      if (rc) return rc;
+      cv.base = c->work.ptr;
+      continue;
+    }
+    if (hip_check(hipMemcpyAsync(d_p, p, C * 4, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
+    if (q && hip_check(hipMemcpyAsync(d_q, q, C * 4, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
+    if (!compute_env && hip_check(hipMemcpyAsync(d_env, env, 2 * ((size_t)L1 + 1) * 4, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
+    int rc = nw_launch(L1, L2, d_p, d_q, th, d_env, compute_env, d_dp, d_tr, d_al, d_score, c->stream);
+    if (rc) return rc;
+    if (compute_env && hip_check(hipMemcpyAsync(env, d_env, 2 * ((size_t)L1 + 1) * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+    float s = 0;
+    if (decode) {
+      if (hip_check(hipMemcpyAsync(al, d_al, (size_t)L1 * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+      if (hip_check(hipMemcpyAsync(&s, d_score, 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+    }
+    if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
+    if (decode && score) *score = s;
+  }
+  return DAFS_HIP_OK;
+}
+
+extern "C" int dafs_hip_nw_envelope(dafs_hip_ctx* c, float th, uint32_t L1, uint32_t L2, const float* p, uint32_t* env) {
+  return nw_common(c, th, L1, L2, p, nullptr, env, 1, 0, nullptr, nullptr);
+}
+
+extern "C" int dafs_hip_nw_decode(dafs_hip_ctx* c, float th, uint32_t L1, uint32_t L2, const float* p, const float* q,
+                                  const uint32_t* env, uint32_t* al, float* score) {
+  if (!al) return DAFS_HIP_EINVAL;
+  return nw_common(c, th, L1, L2, p, q, (uint32_t*)env, 0, 1, al, score);
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-node solver
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct geom {  // host-side geometry of one child alignment
+  std::vector<uint32_t> rank, idx, idxoff;
+};
+
+int make_geom(const dafs_hip_ctx* c, uint32_t n, uint32_t L, const uint32_t* seq, const uint8_t* mask, geom& g) {
+  g.rank.assign((size_t)n * L, DAFS_HIP_NONE);
+  g.idxoff.resize(n);
+  g.idx.clear();
+  for (uint32_t r = 0; r < n; ++r) {
+    if (seq[r] >= c->len.size()) return DAFS_HIP_EINVAL;
+    g.idxoff[r] = (uint32_t)g.idx.size();
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < L; ++i)
+      if (mask[(size_t)r * L + i]) { g.rank[(size_t)r * L + i] = k++; g.idx.push_back(i); }
+    if (k != c->len[seq[r]]) return DAFS_HIP_EINVAL;  // the mask must place every residue
+  }
+  return DAFS_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" void dafs_hip_dd_default_params(dafs_dd_params* p) {
+  if (!p) return;
+  p->w = 4.0f; p->eta0 = 0.5f; p->th_a = 0.01f; p->th_s = 0.2f; p->t_max = 600; p->force_iters = 0;  // dafs.cpp:1612-1640
+}
+
+extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, const dafs_dd_params* prm,
+                                    dafs_node_output* out) {
+  if (!c || !in || !prm || !out || nnodes == 0) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  const mp_store& mps = c->mp[c->cur_mp];
+  const bp_store& bps = c->bp[c->cur_bp];
+  const uint32_t nseq = (uint32_t)c->len.size();
+  if (!mps.valid || !bps.valid || mps.n_tasks != (uint64_t)nseq * (nseq - 1) / 2) return DAFS_HIP_EINVAL;
+  dd_params dp;
+  dp.w = prm->w; dp.eta0 = prm->eta0; dp.th_a = prm->th_a; dp.th_s = prm->th_s; dp.t_max = prm->t_max; dp.force_iters = prm->force_iters;
+
+  // ---- host geometry ----
+  std::vector<geom> g1(nnodes), g2(nnodes);
+  for (uint32_t b = 0; b < nnodes; ++b) {
+    const dafs_node_input& ni = in[b];
+    if (!ni.n1 || !ni.n2 || !ni.len1 || !ni.len2 || !ni.seq1 || !ni.seq2 || !ni.mask1 || !ni.mask2) return DAFS_HIP_EINVAL;
+    int rc;
+    if ((rc = make_geom(c, ni.n1, ni.len1, ni.seq1, ni.mask1, g1[b]))) return rc;
+    if ((rc = make_geom(c, ni.n2, ni.len2, ni.seq2, ni.mask2, g2[b]))) return rc;
+  }
+
+  // ---- carve workspace A (two passes: size, then pointers) ----
+  std::vector<dd_node> nodes(nnodes);
+  std::vector<region> fills;
+  carver cv;
+  for (int pass = 0; pass < 2; ++pass) {
+    cv.used = 0;
+    fills.clear();
+    for (uint32_t b = 0; b < nnodes; ++b) {
+      const dafs_node_input& ni = in[b];
+      dd_node& nd = nodes[b];
+      memset(&nd, 0, sizeof nd);
+      const uint32_t L1 = ni.len1, L2 = ni.len2;
+      nd.n1 = ni.n1; nd.n2 = ni.n2; nd.L1 = L1; nd.L2 = L2;
+      const size_t XX = (size_t)L1 * L1, YY = (size_t)L2 * L2, ZZ = (size_t)L1 * L2, T = (size_t)(L1 + 1) * (L2 + 1);
+      nd.seq1 = cv.take<uint32_t>(ni.n1); nd.seq2 = cv.take<uint32_t>(ni.n2);
+      nd.rank1 = cv.take<uint32_t>((size_t)ni.n1 * L1); nd.rank2 = cv.take<uint32_t>((size_t)ni.n2 * L2);
+      nd.idx1 = cv.take<uint32_t>(g1[b].idx.size() + 1); nd.idx2 = cv.take<uint32_t>(g2[b].idx.size() + 1);
+      nd.idxoff1 = cv.take<uint32_t>(ni.n1); nd.idxoff2 = cv.take<uint32_t>(ni.n2);
+      // zero-filled block: posteriors, multipliers, flags
+      const size_t z0 = (cv.used + 255) & ~(size_t)255;
+      nd.p_x = cv.take<float>(XX); nd.p_y = cv.take<float>(YY); nd.p_z = cv.take<float>(ZZ);
+      nd.q_x = cv.take<float>(XX); nd.q_y = cv.take<float>(YY); nd.q_z = cv.take<float>(ZZ);
+      nd.cz_flag = cv.take<uint8_t>(ZZ);
+      nd.cx_flag = cv.take<uint8_t>(XX / 2 + 2); nd.cy_flag = cv.take<uint8_t>(YY / 2 + 2);
+      fills.push_back({z0, cv.used - z0, 0});
+      // -1-filled block: dense id maps
+      const size_t m0 = (cv.used + 255) & ~(size_t)255;
+      nd.xmap = cv.take<int32_t>(XX); nd.ymap = cv.take<int32_t>(YY); nd.zmap = cv.take<int32_t>(ZZ);
+      fills.push_back({m0, cv.used - m0, 0xFF});
+      carve_nuss(cv, L1, nd.wx);
+      carve_nuss(cv, L2, nd.wy);
+      nd.dp_z = cv.take<float>(T); nd.tr_z = cv.take<uint8_t>(T);
+      nd.env = cv.take<uint32_t>(2 * ((size_t)L1 + 1));
+      nd.px_ptr = cv.take<uint32_t>((size_t)L1 + 2); nd.px_j = cv.take<uint32_t>(XX / 2 + 2);
+      nd.py_ptr = cv.take<uint32_t>((size_t)L2 + 2); nd.py_l = cv.take<uint32_t>(YY / 2 + 2);
+      nd.pz_ptr = cv.take<uint32_t>((size_t)L1 + 2); nd.pz_k = cv.take<uint32_t>(ZZ + 1);
+      nd.cz_ptr = cv.take<uint32_t>((size_t)L1 + 2); nd.cz_k = cv.take<uint32_t>(ZZ + 1);
+      nd.cbp_cnt = cv.take<uint32_t>(XX / 2 + 2);
+      nd.tx = cv.take<int32_t>(XX / 2 + 2); nd.ty = cv.take<int32_t>(YY / 2 + 2); nd.tz = cv.take<int32_t>(ZZ + 1);
+      nd.x = cv.take<uint32_t>((size_t)L1 + 2); nd.y = cv.take<uint32_t>((size_t)L2 + 2); nd.z = cv.take<uint32_t>((size_t)L1 + 2);
+      nd.score = cv.take<float>(1); nd.info = cv.take<uint32_t>(4);
+    }
+    if (pass == 0) {
+      int rc = c->work.reserve(cv.used + 256);
+      if (rc) return rc;
+      cv.base = c->work.ptr;
+    }
+  }
+  // ---- upload geometry, fill, describe ----
+  for (const region& r : fills)
+    if (hip_check(hipMemsetAsync(c->work.ptr + r.off, r.value, r.bytes, c->stream))) return DAFS_HIP_ELAUNCH;
+  for (uint32_t b = 0; b < nnodes; ++b) {
+    const dafs_node_input& ni = in[b];
+    const dd_node& nd = nodes[b];
+    auto up = [&](const void* dst, const void* src, size_t bytes) {
+      return bytes == 0 || !hip_check(hipMemcpyAsync((void*)dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    };
+    bool ok = up(nd.seq1, ni.seq1, ni.n1 * 4) && up(nd.seq2, ni.seq2, ni.n2 * 4) &&
+              up(nd.rank1, g1[b].rank.data(), g1[b].rank.size() * 4) && up(nd.rank2, g2[b].rank.data(), g2[b].rank.size() * 4) &&
+              up(nd.idx1, g1[b].idx.data(), g1[b].idx.size() * 4) && up(nd.idx2, g2[b].idx.data(), g2[b].idx.size() * 4) &&
+              up(nd.idxoff1, g1[b].idxoff.data(), ni.n1 * 4) && up(nd.idxoff2, g2[b].idxoff.data(), ni.n2 * 4);
+    if (!ok) return DAFS_HIP_ELAUNCH;
+  }
+  int rc;
+  if ((rc = c->d_nodes.upload(nodes.data(), nnodes, c->stream))) return rc;  // synchronises: host vectors stay valid until here
+  const mp_store_dev mpv = mps.view(c->d_len.ptr, nseq);
+  const bp_store_dev bpv = bps.view();
+  if ((rc = dd_avg_launch(c->d_nodes.ptr, nnodes, mpv, bpv, c->stream))) return rc;
+  if ((rc = dd_lists_launch(c->d_nodes.ptr, nnodes, dp, c->stream))) return rc;
+  // ---- consensus base-pair counts -> workspace B ----
+  std::vector<uint32_t> info(4 * (size_t)nnodes);
+  for (uint32_t b = 0; b < nnodes; ++b)
+    if (hip_check(hipMemcpyAsync(&info[4 * (size_t)b], nodes[b].info, 16, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+  if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
+  carver cb;
+  for (int pass = 0; pass < 2; ++pass) {
+    cb.used = 0;
+    for (uint32_t b = 0; b < nnodes; ++b) {
+      const uint32_t ncbp = info[4 * (size_t)b];
+      nodes[b].ncbp_cap = ncbp;
+      nodes[b].cbp = cb.take<uint32_t>((size_t)8 * ncbp + 8);
+      nodes[b].sw = cb.take<float>((size_t)ncbp + 1);
+    }
+    if (pass == 0) {
+      if ((rc = c->work2.reserve(cb.used + 256))) return rc;
+      cb.base = c->work2.ptr;
+    }
+  }
+  if ((rc = c->d_nodes.upload(nodes.data(), nnodes, c->stream))) return rc;
+  if ((rc = dd_cbp_fill_launch(c->d_nodes.ptr, nnodes, dp, c->stream))) return rc;
+  if ((rc = dd_solve_launch(c->d_nodes.ptr, nnodes, dp, c->stream))) return rc;
+  // ---- results ----
+  std::vector<float> score(nnodes);
+  for (uint32_t b = 0; b < nnodes; ++b) {
+    const dd_node& nd = nodes[b];
+    auto down = [&](void* dst, const void* src, size_t bytes) {
+      return !dst || !hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    };
+    bool ok = down(out[b].x, nd.x, (size_t)nd.L1 * 4) && down(out[b].y, nd.y, (size_t)nd.L2 * 4) && down(out[b].z, nd.z, (size_t)nd.L1 * 4) &&
+              down(&score[b], nd.score, 4) && down(&info[4 * (size_t)b], nd.info, 16);
+    if (!ok) return DAFS_HIP_ELAUNCH;
+  }
+  if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
+  for (uint32_t b = 0; b < nnodes; ++b) {
+    out[b].score = score[b];
+    out[b].ncbp = info[4 * (size_t)b];
+    out[b].iterations = info[4 * (size_t)b + 1];
+    out[b].violated = info[4 * (size_t)b + 2];
+    if (info[4 * (size_t)b + 3]) return DAFS_HIP_ELAUNCH;  // alignment traceback left the envelope
+  }
+  return DAFS_HIP_OK;
+}
+
+// Averaged base-pairing matrix of an alignment and its MEA structure: the final step of
+// DAFS::run (dafs.cpp:1857-1871) without the RNAalifold term.  p_out (len*len,
+// optional) receives the averaged matrix.
+extern "C" int dafs_hip_consensus_structure(dafs_hip_ctx* c, uint32_t n, uint32_t len, const uint32_t* seq, const uint8_t* mask,
+                                            float th, uint32_t* ss, float* score, float* p_out) {
+  if (!c || !n || !len || !seq || !mask || !ss) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  const bp_store& bps = c->bp[c->cur_bp];
+  if (!bps.valid) return DAFS_HIP_EINVAL;
+  geom g;
+  int rc;
+  if ((rc = make_geom(c, n, len, seq, mask, g))) return rc;
+  dd_node nd;
+  carver cv;
+  const size_t LL = (size_t)len * len;
+  uint32_t* d_ss = nullptr;
+  for (int pass = 0; pass < 2; ++pass) {
+    cv.used = 0;
+    memset(&nd, 0, sizeof nd);
+    nd.n1 = n; nd.L1 = len;
+    nd.seq1 = cv.take<uint32_t>(n);
+    nd.rank1 = cv.take<uint32_t>((size_t)n * len);
+    nd.idx1 = cv.take<uint32_t>(g.idx.size() + 1);
+    nd.idxoff1 = cv.take<uint32_t>(n);
+    nd.p_x = cv.take<float>(LL);
+    carve_nuss(cv, len, nd.wx);
+    d_ss = cv.take<uint32_t>((size_t)len + 1);
+    nd.score = cv.take<float>(1);
+    if (pass == 0) {
+      if ((rc = c->work.reserve(cv.used + 256))) return rc;
+      cv.base = c->work.ptr;
+    }
+  }
+  if (hip_check(hipMemsetAsync(nd.p_x, 0, LL * 4, c->stream))) return DAFS_HIP_ELAUNCH;
+  if (hip_check(hipMemcpyAsync((void*)nd.seq1, seq, n * 4, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
+  if (hip_check(hipMemcpyAsync((void*)nd.rank1, g.rank.data(), g.rank.size() * 4, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
+  if (hip_check(hipMemcpyAsync((void*)nd.idx1, g.idx.data(), g.idx.size() * 4, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
+  if (hip_check(hipMemcpyAsync((void*)nd.idxoff1, g.idxoff.data(), n * 4, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
+  if ((rc = c->d_nodes.upload(&nd, 1, c->stream))) return rc;
+  mp_store_dev none;
+  memset(&none, 0, sizeof none);
+  if ((rc = dd_avg_launch(c->d_nodes.ptr, 1, none, bps.view(), c->stream))) return rc;
+  if ((rc = nussinov_launch(len, nd.p_x, nullptr, 0.0f, th, nd.wx, d_ss, nd.score, c->stream))) return rc;
+  float s = 0;
+  if (hip_check(hipMemcpyAsync(ss, d_ss, (size_t)len * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+  if (hip_check(hipMemcpyAsync(&s, nd.score, 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+  if (p_out && hip_check(hipMemcpyAsync(p_out, nd.p_x, LL * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+  if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
+  if (score) *score = s;
+  return DAFS_HIP_OK;
+}

@@ -9,6 +9,7 @@
 #include "../../include/dafs_hip.h"
 #include "hip_util.h"
 #include "sparse_view.h"
+#include "dd.h"
 
 namespace dafs {
 
@@ -107,11 +108,14 @@ struct dafs_hip_ctx {
   std::vector<float> sim;
   dafs::dev_buf<float> d_sim;
   dafs::dev_buf<uint32_t> d_pair_x, d_pair_y;
+  // progressive phase workspaces
+  dafs::dev_buf<uint8_t> work, work2;
+  dafs::dev_buf<dafs::dd_node> d_nodes;
   uint32_t max_len() const { uint32_t m = 0; for (uint32_t l : len) m = l > m ? l : m; return m; }
 
   void free_all() {
     codes.release(); d_len.release(); d_seq_rp_off.release(); tasks.release(); scratch.release(); task_sim.release();
-    counters.release(); d_sim.release(); d_pair_x.release(); d_pair_y.release();
+    counters.release(); d_sim.release(); d_pair_x.release(); d_pair_y.release(); work.release(); work2.release(); d_nodes.release();
     for (int k = 0; k < 2; ++k) { mp[k].release(); bp[k].release(); }
   }
 };

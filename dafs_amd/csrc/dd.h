@@ -1,0 +1,59 @@
+// dafs_amd/csrc/dd.h -- device-side descriptors of the progressive phase (dd.hip):
+// one dd_node per guide-tree node being solved, all pointers into device memory.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sparse_view.h"
+
+namespace dafs {
+
+struct nuss_ws {      // SparseNussinov work arrays for one problem of size L
+  float* dp;          // L*L
+  uint32_t* tr;       // L*L
+  uint32_t* ck;       // L*L  candidate list of column j at ck[j*L ..], insertion order (k descending)
+  float* cv;          // L*L
+  uint32_t* cc;       // L    candidates per column
+};
+
+struct dd_node {
+  uint32_t n1, n2, L1, L2;
+  // child alignments: per row the sequence index, per (row, column) the residue rank or NONE,
+  // and per (row, residue) its column
+  const uint32_t *seq1, *seq2, *rank1, *rank2, *idx1, *idx2, *idxoff1, *idxoff2;
+  // averaged posteriors (dafs.cpp:513-607) and Lagrange multipliers
+  float *p_x, *p_y, *p_z, *q_x, *q_y, *q_z;
+  nuss_ws wx, wy;
+  float* dp_z;        // (L1+1)*(L2+1)
+  uint8_t* tr_z;      // (L1+1)*(L2+1)
+  uint32_t* env;      // 2*(L1+1)
+  // sparse structure of p_x / p_y / p_z (> CUTOFF) and of the consensus base pairs
+  int32_t *xmap, *ymap, *zmap;    // dense cell -> entry id (px / py / cz lists) or -1
+  uint32_t *px_ptr, *px_j, *py_ptr, *py_l, *pz_ptr, *pz_k, *cz_ptr, *cz_k;
+  uint8_t *cx_flag, *cy_flag, *cz_flag;
+  uint32_t* cbp_cnt;              // per px entry
+  uint32_t* cbp;                  // 8 per consensus base pair: i j k l pxid pyid zid1 zid2
+  uint32_t ncbp_cap;
+  int32_t *tx, *ty, *tz;          // per entry violation counters
+  float* sw;                      // ncbp: positive s_w, compacted in cbp order
+  // results
+  uint32_t *x, *y, *z;
+  float* score;                   // [1]
+  uint32_t* info;                 // [4]: ncbp, iterations, violated, status
+};
+
+struct dd_params {
+  float w, eta0, th_a, th_s;
+  uint32_t t_max;
+  int force_iters;
+};
+
+int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, mp_store_dev mp, bp_store_dev bp, hipStream_t st);
+int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st);
+int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st);
+int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st);
+// standalone decoders on dense device matrices (one workgroup each)
+int nussinov_launch(uint32_t L, const float* p, const float* q, float w, float th, nuss_ws ws, uint32_t* ss, float* score, hipStream_t st);
+int nw_launch(uint32_t L1, uint32_t L2, const float* p, const float* q, float th, uint32_t* env, int compute_env,
+              float* dp, uint8_t* tr, uint32_t* al, float* score, hipStream_t st);
+
+}  // namespace dafs

@@ -1,0 +1,150 @@
+"""Host-side driver of the whole DAFS run on top of the C ABI -- the Python mirror of
+DAFS::run (reference src/dafs.cpp:1781-1889) used by tests and bench.py.  Everything numeric is
+done by libdafs_hip.so on the GPU; this file only holds the guide tree, the alignment bookkeeping
+(project_alignment) and the output format.  The C++ `dafs` executable (dafs_amd/csrc/cli_main.cpp)
+is the same logic for the drop-in command line."""
+import heapq
+
+import numpy as np
+
+from . import capi
+
+NONE = 0xFFFFFFFF
+
+
+def build_tree(sim):
+    """DAFS::build_tree, src/dafs.cpp:446-492.  Returns (score[2n-1], left, right) with -1 for leaves."""
+    n = sim.shape[0]
+    T = 2 * n - 1
+    score = np.zeros(T, np.float32)
+    left = -np.ones(T, np.int64)
+    right = -np.ones(T, np.int64)
+    d = np.zeros((n, n), np.float32)
+    idx = [-1] * T
+    for i in range(n):
+        idx[i] = i
+    pq = []
+    for i in range(n - 1):
+        for j in range(i + 1, n):
+            d[i, j] = d[j, i] = sim[i, j]
+            heapq.heappush(pq, (-float(sim[i, j]), -i, -j))  # max-heap on (sim, (i, j))
+    cur = n
+    while pq:
+        s, a, b = heapq.heappop(pq)
+        s, a, b = np.float32(-s), -a, -b
+        if idx[a] != -1 and idx[b] != -1:
+            l, r = idx[a], idx[b]
+            idx[a] = idx[b] = -1
+            for i in range(cur):
+                if idx[i] != -1:
+                    ii = idx[i]
+                    v = np.float32(np.float32(d[ii, l] + d[ii, r]) * s) / np.float32(2)
+                    d[ii, l] = d[l, ii] = v
+                    heapq.heappush(pq, (-float(v), -i, -cur))
+            score[cur] = s
+            left[cur], right[cur] = a, b
+            idx[cur] = l
+            cur += 1
+    return score, left, right
+
+
+def tree_string(score, left, right, names, i=None):
+    """print_tree, src/dafs.cpp:495-511 (operator<<(float) == %g)"""
+    if i is None:
+        i = len(score) - 1
+    if left[i] < 0:
+        return names[i]
+    return "[ %g %s %s ]" % (float(score[i]), tree_string(score, left, right, names, left[i]),
+                            tree_string(score, left, right, names, right[i]))
+
+
+def project_alignment(a1, a2, z):
+    """src/dafs.cpp:766-825.  a = (seq_idx[n], mask[n, L])"""
+    s1, m1 = a1
+    s2, m2 = a2
+    L1, L2 = m1.shape[1], m2.shape[1]
+    cols1, cols2 = [], []  # per output column: source column in aln1 / aln2 or -1
+    k = 0
+    for i in range(L1):
+        if z[i] != NONE:
+            while k < z[i]:
+                cols1.append(-1); cols2.append(k); k += 1
+            cols1.append(i); cols2.append(k); k += 1
+        else:
+            cols1.append(i); cols2.append(-1)
+    while k < L2:
+        cols1.append(-1); cols2.append(k); k += 1
+    c1 = np.array(cols1); c2 = np.array(cols2)
+    o1 = np.where(c1[None, :] >= 0, m1[:, np.maximum(c1, 0)], 0).astype(np.uint8)
+    o2 = np.where(c2[None, :] >= 0, m2[:, np.maximum(c2, 0)], 0).astype(np.uint8)
+    return np.concatenate([s1, s2]), np.concatenate([o1, o2], axis=0)
+
+
+class Result:
+    pass
+
+
+def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25, w_pct_s=0.25, th_a=0.01,
+        th_s=0.2, th_s1=None, align_model=capi.ALIGN_PROBCONS, force_iters=0, timers=None):
+    """The whole run.  bp: per-sequence (rowptr, col, val) base-pairing rows (--fold-aux); None
+    computes them with the device fold model."""
+    import time
+    own = ctx is None
+    if own:
+        ctx = capi.Context(0)
+    t = [time.perf_counter()]
+    n = len(seqs)
+    ctx.set_sequences(seqs)
+    if bp is not None:
+        ctx.set_bp(bp)
+    else:
+        ctx.fold_posteriors(0.01)
+    t.append(time.perf_counter())
+    ctx.align_posteriors(align_model, th_a, fetch=False)
+    t.append(time.perf_counter())
+    sim = ctx.sim()
+    ctx.consistency(w_pct_a, w_pct_s)
+    score, left, right = build_tree(sim)
+    t.append(time.perf_counter())
+    res = Result()
+    res.sim = sim
+    res.tree = (score, left, right)
+    res.tree_line = tree_string(score, left, right, names)
+    # progressive phase: solve every node whose children are ready, level by level
+    lens = [len(s) for s in seqs]
+    aln = {i: (np.array([i], np.uint32), np.ones((1, lens[i]), np.uint8)) for i in range(n)}
+    pending = [i for i in range(n, 2 * n - 1)]
+    prm = capi.dd_params(w=w, eta0=eta0, th_a=th_a, th_s=th_s, t_max=t_max, force_iters=force_iters)
+    res.dd_log = {}
+    res.levels = 0
+    while pending:
+        ready = [i for i in pending if left[i] in aln and right[i] in aln]
+        outs = ctx.solve_nodes([(aln[left[i]][0], aln[left[i]][1], aln[right[i]][0], aln[right[i]][1]) for i in ready], prm)
+        for i, o in zip(ready, outs):
+            aln[i] = project_alignment(aln[left[i]], aln[right[i]], o["z"])
+            res.dd_log[i] = (o["iterations"], o["violated"], o["ncbp"], o["score"])
+            del aln[left[i]], aln[right[i]]
+        pending = [i for i in pending if i not in ready]
+        res.levels += 1
+    root = 2 * n - 2
+    sidx, mask = aln[root]
+    t.append(time.perf_counter())
+    _, ss, _ = ctx.consensus_structure(sidx, mask, th_s if th_s1 is None else th_s1)
+    res.ss = ss
+    res.ss_str = capi.make_brackets(ss)
+    order = np.argsort(sidx, kind="stable")  # std::sort(aln) :1876
+    lines = [res.tree_line, ">SS_cons", res.ss_str]
+    res.rows = []
+    for r in order:
+        s = seqs[sidx[r]]
+        it = iter(s)
+        row = "".join(next(it) if m else "-" for m in mask[r])
+        res.rows.append(row)
+        lines += ["> " + names[sidx[r]], row]
+    res.output = "\n".join(lines) + "\n"
+    t.append(time.perf_counter())
+    res.seconds = dict(fold=t[1] - t[0], pair=t[2] - t[1], pct_tree=t[3] - t[2], progressive=t[4] - t[3], final=t[5] - t[4],
+                       total=t[5] - t[0])
+    if own:
+        ctx.close()
+    return res

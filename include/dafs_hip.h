@@ -157,6 +157,65 @@ int dafs_hip_bp_fetch(dafs_hip_ctx* ctx, int relaxed, uint32_t* rowptr, uint32_t
  * ---------------------------------------------------------------------------------------- */
 int dafs_hip_consistency(dafs_hip_ctx* ctx, float w_pct_a, float w_pct_s);
 
+/* ------------------------------------------------------------------------------------------
+ * L1: decoder plugins on dense row-major matrices (host buffers).
+ * dafs_hip_nussinov_decode replaces SparseNussinov::decode(w,p,q,ss) (src/nussinov.cpp:207-298);
+ * with q == NULL it is the final-decode overload decode(p,ss,str) (:300-392, score p-th, w unused;
+ * brackets: dafs_hip_make_brackets).  ss[i] = partner index or DAFS_HIP_NONE.
+ * dafs_hip_nw_envelope replaces SparseNeedlemanWunsch::initialize (src/needleman_wunsch.cpp:198-253):
+ * env[2*i], env[2*i+1] = first/last column of row i, i = 0..L1.
+ * dafs_hip_nw_decode replaces SparseNeedlemanWunsch::decode (:255-422), q may be NULL;
+ * al[i] = aligned column or DAFS_HIP_NONE.
+ * ---------------------------------------------------------------------------------------- */
+int dafs_hip_nussinov_decode(dafs_hip_ctx* ctx, float th, float w, uint32_t L, const float* p, const float* q,
+                             uint32_t* ss, float* score);
+int dafs_hip_nw_envelope(dafs_hip_ctx* ctx, float th, uint32_t L1, uint32_t L2, const float* p, uint32_t* env);
+int dafs_hip_nw_decode(dafs_hip_ctx* ctx, float th, uint32_t L1, uint32_t L2, const float* p, const float* q,
+                       const uint32_t* env, uint32_t* al, float* score);
+/* make_brackets (src/nussinov.cpp:401-413): str needs L+1 bytes. Host-only helper. */
+void dafs_hip_make_brackets(uint32_t L, const uint32_t* ss, char* str);
+
+/* ------------------------------------------------------------------------------------------
+ * L1: fused guide-tree node solver.
+ * One call solves a batch of independent nodes: for each, average the base-pairing and matching
+ * probabilities of the two child alignments (src/dafs.cpp:513-607, no alifold term), enumerate the
+ * consensus base pairs, and run the whole dual-decomposition loop on the device
+ * (DAFS::solve_by_dd, src/dafs.cpp:1006-1295).  Uses the context's current stores (after
+ * dafs_hip_consistency when that was called).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  uint32_t n1, n2;        /* rows (sequences) of the two child alignments                     */
+  uint32_t len1, len2;    /* their column counts                                              */
+  const uint32_t* seq1;   /* [n1] sequence index of each row                                  */
+  const uint32_t* seq2;   /* [n2]                                                             */
+  const uint8_t* mask1;   /* [n1*len1] 1 = residue, 0 = gap (the reference's vector<bool>)    */
+  const uint8_t* mask2;   /* [n2*len2]                                                        */
+} dafs_node_input;
+
+typedef struct {
+  uint32_t* x;            /* [len1] common structure of alignment 1 (may be NULL)             */
+  uint32_t* y;            /* [len2] (may be NULL)                                             */
+  uint32_t* z;            /* [len1] column of alignment 2 aligned to each column of 1         */
+  float score;            /* value solve_by_dd returns (s_prev)                               */
+  uint32_t ncbp, iterations, violated; /* dafs.cpp:1292 log line                             */
+} dafs_node_output;
+
+typedef struct {
+  float w;                /* -w    default 4.0 */
+  float eta0;             /* --eta default 0.5 */
+  float th_a;             /* -u    default 0.01 */
+  float th_s;             /* -t    default 0.2 */
+  uint32_t t_max;         /* -m    default 600 */
+  int force_iters;        /* bench only: ignore the violated==0 exit (never for parity runs)  */
+} dafs_dd_params;
+void dafs_hip_dd_default_params(dafs_dd_params* p);
+int dafs_hip_solve_nodes(dafs_hip_ctx* ctx, uint32_t nnodes, const dafs_node_input* in, const dafs_dd_params* prm,
+                         dafs_node_output* out);
+/* Final common structure of an alignment (src/dafs.cpp:1857-1871 without the RNAalifold term):
+ * averaged base-pairing matrix -> SparseNussinov::decode(p,ss,str) with threshold th. */
+int dafs_hip_consensus_structure(dafs_hip_ctx* ctx, uint32_t n, uint32_t len, const uint32_t* seq, const uint8_t* mask,
+                                 float th, uint32_t* ss, float* score, float* p_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,108 @@
+"""GPU parity for the progressive phase: decoders against the golden
+vectors and the oracle; averaging + solve_by_dd + projection (a19, a20, a23) and the whole run
+against the oracle pipeline and the known answers."""
+import os
+
+import numpy as np
+import pytest
+
+from dafs_amd import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from dafs_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def test_decoders_golden(ctx):
+    z = np.load(os.path.join(G, "decoders.npz"))
+    for k in range(int(z["n"])):
+        p, q, w, th = z["p%d" % k], z["q%d" % k], float(z["w%d" % k]), float(z["th%d" % k])
+        s, ss = ctx.nussinov(p, q, th, w)
+        assert np.float32(s).tobytes() == np.float32(z["s%d" % k]).tobytes() and np.array_equal(ss, z["ss%d" % k]), k
+        s, ss = ctx.nussinov(p, None, th)
+        assert np.float32(s).tobytes() == np.float32(z["sf%d" % k]).tobytes() and np.array_equal(ss, z["ssf%d" % k]), k
+        from dafs_amd import capi
+        assert capi.make_brackets(ss) == str(z["br%d" % k])
+        pz, qz, tha = z["pz%d" % k], z["qz%d" % k], float(z["tha%d" % k])
+        s, al = ctx.nw(pz, qz, tha)
+        assert np.float32(s).tobytes() == np.float32(z["sz%d" % k]).tobytes() and np.array_equal(al, z["al%d" % k]), k
+        s, al = ctx.nw(pz, None, tha)
+        assert np.float32(s).tobytes() == np.float32(z["szf%d" % k]).tobytes() and np.array_equal(al, z["alf%d" % k]), k
+
+
+def test_decoders_fuzz_vs_oracle(ctx, oracle):
+    rng = np.random.default_rng(77)
+    for t in range(25):
+        L = int(rng.choice([1, 2, 3, 4, 7, 33, 90, 200]))
+        L2 = int(rng.choice([1, 2, 5, 31, 100, 170]))
+        dens = float(rng.choice([0.0, 0.03, 0.2]))
+        p = (rng.random((L, L)) * (rng.random((L, L)) < dens)).astype(np.float32)
+        if t % 2:
+            p = (np.round(p * 4) / 4).astype(np.float32)
+        q = ((rng.random((L, L)) - 0.4) * (rng.random((L, L)) < 0.3)).astype(np.float32)
+        w, th = float(rng.choice([4.0, 1.3333334])), float(rng.choice([0.2, 0.05]))
+        a, b = ctx.nussinov(p, q, th, w), oracle.nussinov(p, q, th, w)
+        assert np.float32(a[0]).tobytes() == np.float32(b[0]).tobytes() and np.array_equal(a[1], b[1]), (t, L)
+        pz = (rng.random((L, L2)) * (rng.random((L, L2)) < max(dens, 0.02))).astype(np.float32)
+        qz = (rng.random((L, L2)) * (rng.random((L, L2)) < 0.2)).astype(np.float32)
+        env = ctx.nw_envelope(pz, 0.01)
+        assert np.array_equal(env, oracle.nw_envelope(pz, 0.01)), (t, L, L2)
+        a, b = ctx.nw(pz, qz, 0.01, env), oracle.nw(pz, qz, 0.01)
+        assert np.float32(a[0]).tobytes() == np.float32(b[0]).tobytes() and np.array_equal(a[1], b[1]), (t, L, L2)
+
+
+def _run_both(oracle, names, seqs, bp, **kw):
+    from dafs_amd import pipeline
+    okw = dict(fold_model=1)
+    for k in ("w", "eta0", "t_max", "w_pct_a", "w_pct_s", "th_a", "th_s"):
+        if k in kw:
+            okw[k] = kw[k]
+    if "th_s" in kw:
+        okw["th_s1"] = kw["th_s"]
+    pl = oracle.pipeline(names, seqs, oracle.params(**okw), bp=bp)
+    pl.phase1(); pl.phase2()
+    want = pl.output()
+    it, vi = pl.dd_log()
+    pl.close()
+    got = pipeline.run(names, seqs, bp=bp, **kw)
+    return want, (it, vi), got
+
+
+def test_rf00005_whole_run(oracle):
+    import test_oracle_cpu as t
+    ka = t.known()
+    recs = oracle.fasta(os.path.join(G, "RF00005_0.fa"))
+    names, seqs = [n for n, _ in recs], [s for _, s in recs]
+    want, (it, vi), got = _run_both(oracle, names, seqs, t._golden_bp(seqs))
+    assert got.tree_line == ka["rf00005.probcons.tree"]
+    assert got.rows[0] == ka["rf00005.probcons.contrafold.first_row"]
+    assert got.rows[-1] == ka["rf00005.probcons.contrafold.last_row"]
+    assert got.output == want
+    assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
+
+
+@pytest.mark.parametrize("n,length,fam,seed", [(6, 50, True, 1), (8, 90, False, 2), (5, 140, True, 3), (2, 30, False, 4)])
+def test_synthetic_whole_run(oracle, n, length, fam, seed):
+    from test_pct_gpu import random_bp
+    recs = synth.family_set(n, length, seed=seed) if fam else synth.random_set(n, length, seed=seed)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    want, (it, vi), got = _run_both(oracle, names, seqs, random_bp(seqs, seed, density=0.02))
+    assert got.output == want
+    assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
+
+
+def test_iteration_cap_and_params(oracle):
+    from test_pct_gpu import random_bp
+    recs = synth.family_set(6, 70, seed=9)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    bp = random_bp(seqs, 9, density=0.05)
+    for kw in (dict(t_max=3), dict(w=2.0, eta0=0.25, th_s=0.1), dict(t_max=1, w_pct_a=0.0)):
+        want, (it, vi), got = _run_both(oracle, names, seqs, bp, **kw)
+        assert got.output == want, kw
