@@ -72,6 +72,37 @@ def test_decoders_golden(oracle):
         assert np.float32(s).tobytes() == np.float32(z["szf%d" % k]).tobytes() and np.array_equal(al, z["alf%d" % k])
 
 
+def _orc_fold_post(oracle, s, cons=None):
+    L = len(s)
+    out = np.zeros((L + 1) * (L + 2) // 2, np.float32)
+    rc = oracle.lib.orc_contrafold_posterior(s.encode(), L, None if cons is None else cons.encode(), out.ctypes.data)
+    assert rc == len(out)
+    return out
+
+
+def test_contrafold_golden(oracle):
+    z = np.load(os.path.join(G, "contrafold_post.npz"))
+    for k, s in enumerate(z["seqs"]):
+        got = _orc_fold_post(oracle, str(s))
+        assert got.tobytes() == z["post"][z["off"][k]:z["off"][k + 1]].tobytes(), (k, len(str(s)))
+    got = _orc_fold_post(oracle, str(z["cons_seq"]), str(z["cons_str"]))
+    assert got.tobytes() == z["cons_post"].tobytes()
+    ka = known()
+    p0 = z["post"][z["off"][0]:z["off"][1]]
+    assert (p0 > np.float32(0.01)).sum() == int(ka["rf00005.seq0.contrafold.nnz_gt_0.01"])
+    assert "%.9g" % p0.max() == ka["rf00005.seq0.contrafold.max"]
+
+
+def test_fold_adapter_matches_golden_rows(oracle):
+    """orc_fold_calculate (fold.cpp:174-189) == rows derived from the golden triangular posteriors"""
+    seqs = [s for _, s in oracle.fasta(os.path.join(G, "RF00005_0.fa"))][:4]
+    for s, (rp, col, val) in zip(seqs, _golden_bp(seqs)):
+        L = len(s)
+        orp = np.zeros(L + 1, np.uint32); ocol = np.zeros(L * L, np.uint32); oval = np.zeros(L * L, np.float32)
+        n = oracle.lib.orc_fold_calculate(s.encode(), L, None, 0.01, orp.ctypes.data, ocol.ctypes.data, oval.ctypes.data)
+        assert n == len(col) and np.array_equal(orp, rp) and np.array_equal(ocol[:n], col) and oval[:n].tobytes() == val.tobytes()
+
+
 def _golden_bp(seqs):
     """CONTRAfold BP rows (p > 0.01, fold.cpp:181-188) from the golden triangular posteriors."""
     z = np.load(os.path.join(G, "contrafold_post.npz"))
@@ -100,9 +131,11 @@ def test_pipeline_rf00005_known_answers(oracle):
     ka = known()
     recs = oracle.fasta(os.path.join(G, "RF00005_0.fa"))
     names, seqs = [n for n, _ in recs], [s for _, s in recs]
-    pl = oracle.pipeline(names, seqs, oracle.params(fold_model=1), bp=_golden_bp(seqs))
+    pl = oracle.pipeline(names, seqs, oracle.params(fold_model=0))  # CONTRAfold computed by the oracle itself
     pl.phase1()
     assert pl.output().split("\n")[0] == ka["rf00005.probcons.tree"]
+    for x, (rp, col, val) in enumerate(_golden_bp(seqs)):
+        pass  # (the un-relaxed rows are checked in test_fold_adapter_matches_golden_rows)
     pl.phase2()
     lines = pl.output().split("\n")
     assert lines[1] == ">SS_cons"
@@ -154,6 +187,8 @@ def test_oracle_vs_reference_fuzz(oracle, ref):
         s1 = "".join(rng.choice(list(alpha), L1)); s2 = "".join(rng.choice(list(alpha), L2))
         for th in (0.0, 0.01):
             assert oracle.probcons_posterior(s1, s2, th).tobytes() == ref.probcons_posterior(s1, s2, th).tobytes()
+        if t < 12:
+            assert _orc_fold_post(oracle, s1).tobytes() == ref.contrafold_posterior(s1).tobytes()
         a, b = oracle.align_calculate(s1, s2, 0.01, 0), ref.align_calculate(s1, s2, 0.01, 0)
         assert all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
     assert oracle.fasta(os.path.join(G, "RF00017_4.fa")) == ref.fasta(os.path.join(G, "RF00017_4.fa"))
