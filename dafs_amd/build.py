@@ -16,7 +16,7 @@ OBJ = os.path.join(HERE, "_obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the reference CPU build has no FMA contraction; bit-exact parity needs the same.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall",
-         "-Wno-unused-function", "-fno-fast-math"]
+         "-Wno-unused-function", "-Wno-missing-braces", "-fno-fast-math"]
 
 
 def sources():

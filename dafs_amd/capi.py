@@ -74,6 +74,9 @@ _get_sim = _sig("dafs_hip_get_sim", C.c_int, [C.c_void_p, C.c_void_p])
 _set_bp = _sig("dafs_hip_set_bp", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
 _bp_result_size = _sig("dafs_hip_bp_result_size", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
 _bp_fetch = _sig("dafs_hip_bp_fetch", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
+_fold_posteriors = _sig("dafs_hip_fold_posteriors", C.c_int, [C.c_void_p, C.c_int, C.c_float])
+_fold_posterior_dense = _sig("dafs_hip_fold_posterior_dense", C.c_int,
+                             [C.c_void_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_void_p, C.POINTER(C.c_float)])
 _consistency = _sig("dafs_hip_consistency", C.c_int, [C.c_void_p, C.c_float, C.c_float])
 
 
@@ -228,6 +231,18 @@ class Context:
             r0 += int(L) + 1
             e0 += n
         return out
+
+    def fold_posteriors(self, th=0.01, model=0):
+        """CONTRAfold base-pairing posteriors of every sequence -> the un-relaxed bp store"""
+        check(_fold_posteriors(self._h, model, th))
+
+    def fold_posterior_dense(self, seq, constraint=None):
+        b = seq.encode() if isinstance(seq, str) else bytes(seq)
+        L = len(b)
+        post = np.zeros((L + 1) * (L + 2) // 2, np.float32)
+        logz = C.c_float()
+        check(_fold_posterior_dense(self._h, b, L, None if constraint is None else constraint.encode(), post.ctypes.data, C.byref(logz)))
+        return post, np.float32(logz.value)
 
     def consistency(self, w_pct_a=0.25, w_pct_s=0.25):
         check(_consistency(self._h, w_pct_a, w_pct_s))

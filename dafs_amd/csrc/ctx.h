@@ -108,6 +108,11 @@ struct dafs_hip_ctx {
   std::vector<float> sim;
   dafs::dev_buf<float> d_sim;
   dafs::dev_buf<uint32_t> d_pair_x, d_pair_y;
+  // CONTRAfold workspaces
+  bool cf_params_ready = false;
+  dafs::dev_buf<uint8_t> d_cf_params, cf_seqs, cf_codes;
+  dafs::dev_buf<int> cf_iws, cf_cons;
+  dafs::dev_buf<float> cf_fws, cf_post, cf_logz;
   // progressive phase workspaces
   dafs::dev_buf<uint8_t> work, work2;
   dafs::dev_buf<dafs::dd_node> d_nodes;
@@ -116,6 +121,7 @@ struct dafs_hip_ctx {
   void free_all() {
     codes.release(); d_len.release(); d_seq_rp_off.release(); tasks.release(); scratch.release(); task_sim.release();
     counters.release(); d_sim.release(); d_pair_x.release(); d_pair_y.release(); work.release(); work2.release(); d_nodes.release();
+    d_cf_params.release(); cf_seqs.release(); cf_codes.release(); cf_iws.release(); cf_cons.release(); cf_fws.release(); cf_post.release(); cf_logz.release();
     for (int k = 0; k < 2; ++k) { mp[k].release(); bp[k].release(); }
   }
 };

@@ -149,6 +149,18 @@ int dafs_hip_set_bp(dafs_hip_ctx* ctx, const uint32_t* rowptr, const uint32_t* c
 int dafs_hip_bp_result_size(dafs_hip_ctx* ctx, int relaxed, uint64_t* total_nnz, uint64_t* total_rowptr);
 int dafs_hip_bp_fetch(dafs_hip_ctx* ctx, int relaxed, uint32_t* rowptr, uint32_t* col, float* val);
 
+/* Batch hook replacing Fold::Model::calculate(const vector<Fasta>&, vector<BP>&)
+ * (src/fold.cpp:60-68) for -s CONTRAfold (CONTRAfold::calculate, src/fold.cpp:174-189): inside /
+ * outside / posterior of every sequence on the device, rows with p > th kept (reference CUTOFF
+ * 0.01, src/dafs.cpp:1704).  Fills the same store dafs_hip_set_bp fills. */
+int dafs_hip_fold_posteriors(dafs_hip_ctx* ctx, int model, float th);
+/* Single-sequence call replacing CONTRAfold<float>::ComputePosterior (src/contrafold/wrapper.cpp:181-200)
+ * and, with a constraint string of len chars from "?.()" ('?' free, '.' unpaired, brackets forced),
+ * Fold::Model::calculate(seq, str, bp) (src/fold.cpp:191-207).  post: (len+1)(len+2)/2 floats,
+ * upper-triangular rows i = 0..len, columns j = i..len; logz (optional): log partition function. */
+int dafs_hip_fold_posterior_dense(dafs_hip_ctx* ctx, const char* seq, uint32_t len, const char* constraint, float* post,
+                                  float* logz);
+
 /* ------------------------------------------------------------------------------------------
  * L1: probabilistic consistency transforms.
  * Replaces DAFS::relax_basepairing_probability (src/dafs.cpp:326-375) and
