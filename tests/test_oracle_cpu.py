@@ -45,6 +45,32 @@ def test_probcons_mp_golden(oracle):
         assert d.tobytes() == z["dense%d" % k].tobytes()
 
 
+def test_contralign_mp_golden(oracle):
+    z = np.load(os.path.join(G, "contralign_mp.npz"))
+    for s1, s2, rp, col, val in _cases("contralign_mp.npz"):
+        orp, ocol, oval = oracle.align_calculate(s1, s2, float(z["th"]), 1)
+        assert np.array_equal(orp, rp) and np.array_equal(ocol, col) and oval.tobytes() == val.tobytes()
+    ka = known()
+    seqs = [s for _, s in oracle.fasta(os.path.join(G, "RF00005_0.fa"))]
+    rp, col, val = oracle.align_calculate(seqs[0], seqs[1], 0.01, 1)
+    assert len(col) == int(ka["rf00005.seq0_seq1.contralign.nnz"])
+    assert col[0] == 0 and "%.9g" % val[0] == ka["rf00005.seq0_seq1.contralign.first"]
+
+
+def test_pipeline_rf00005_contralign_known_answers(oracle):
+    """-a CONTRAlign -s CONTRAfold --no-alifold"""
+    ka = known()
+    recs = oracle.fasta(os.path.join(G, "RF00005_0.fa"))
+    names, seqs = [n for n, _ in recs], [s for _, s in recs]
+    pl = oracle.pipeline(names, seqs, oracle.params(fold_model=0, align_model=1))
+    pl.phase1(); pl.phase2()
+    lines = pl.output().split("\n")
+    assert lines[0] == ka["rf00005.contralign.tree"]
+    assert len(lines[4]) == int(ka["rf00005.contralign.contrafold.columns"])
+    assert lines[4] == ka["rf00005.contralign.contrafold.first_row"]
+    pl.close()
+
+
 def test_probcons_known_scalars(oracle):
     ka = known()
     seqs = [s for _, s in oracle.fasta(os.path.join(G, "RF00005_0.fa"))]
