@@ -92,6 +92,34 @@ extern "C" void dafs_hip_pairhmm3_default_model(dafs_pairhmm3_model* m) {
   for (int i = 0; i < 8; ++i) m->ins[i] = i < 6 ? logf(emitSingle[i]) : single_other;
 }
 
+// CONTRAlign RNA defaults (reference src/contralign/Defaults.ipp:389-419) expanded to the physical
+// tables InferenceEngine::RegisterParameters ties them to (src/contralign/InferenceEngine.ipp:139-226).
+extern "C" void dafs_hip_pairhmm5_default_model(dafs_pairhmm5_model* m) {
+  enum { M = 0, IX = 1, IY = 2, I2X = 3, I2Y = 4 };
+  memset(m, 0, sizeof *m);
+  // match_XY, name = lexicographic min of XY / YX: AA AC AG AU CC CG CU GG GU UU
+  static const float mt[10] = {(float)(0.5256508867), (float)(-0.4090640200), (float)(-0.2502759109), (float)(-0.3252306723),
+                               (float)(0.6665219366), (float)(-0.3289391181), (float)(-0.1326088918), (float)(0.6684676551),
+                               (float)(-0.3565888168), (float)(0.4590520450)};
+  int t = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = i; j < 4; ++j) m->match[i][j] = m->match[j][i] = mt[t++];
+  static const float ins[4] = {(float)(-0.0025219272), (float)(-0.0831389156), (float)(-0.0744397065), (float)(-0.0129005460)};
+  for (int i = 0; i < 4; ++i) m->insert[i] = ins[i];
+  m->single[M] = (float)(0.3959924457);
+  m->single[IX] = m->single[IY] = (float)(-0.4431756229);
+  m->single[I2X] = m->single[I2Y] = (float)(-0.3488104904);
+  const float m2m = (float)(2.5057567100), m2i = (float)(-1.2423961130), iext = (float)(1.8676346730), ichg = (float)(-6.9696754440);
+  const float m2i2 = (float)(0.1970448791), i2ext = (float)(1.0140265830), i2chg = (float)(-7.3469687820);
+  m->pair[M][M] = m2m;
+  m->pair[M][IX] = m->pair[M][IY] = m->pair[IX][M] = m->pair[IY][M] = m2i;
+  m->pair[IX][IX] = m->pair[IY][IY] = iext;
+  m->pair[IX][IY] = m->pair[IY][IX] = ichg;
+  m->pair[M][I2X] = m->pair[M][I2Y] = m->pair[I2X][M] = m->pair[I2Y][M] = m2i2;
+  m->pair[I2X][I2X] = m->pair[I2Y][I2Y] = i2ext;
+  m->pair[I2X][I2Y] = m->pair[I2Y][I2X] = i2chg;
+}
+
 // ---------------------------------------------------------------------------------------------
 extern "C" int dafs_hip_create(int device, dafs_hip_ctx** out) {
   if (!out) return DAFS_HIP_EINVAL;

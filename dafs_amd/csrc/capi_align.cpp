@@ -23,7 +23,7 @@ static void pair_from_index(uint64_t p, uint32_t n, uint32_t* i, uint32_t* j) {
 
 extern "C" int dafs_hip_align_posteriors(dafs_hip_ctx* c, int model, float th, uint64_t pair_begin, uint64_t pair_end) {
   if (!c || c->len.empty() || !(th >= 0.0f)) return DAFS_HIP_EINVAL;
-  if (model != DAFS_ALIGN_PROBCONS) return DAFS_HIP_EINVAL;
+  if (model != DAFS_ALIGN_PROBCONS && model != DAFS_ALIGN_CONTRALIGN) return DAFS_HIP_EINVAL;
   if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
   const uint32_t n = (uint32_t)c->len.size();
   const uint64_t all = (uint64_t)n * (n - 1) / 2;
@@ -78,7 +78,8 @@ extern "C" int dafs_hip_align_posteriors(dafs_hip_ctx* c, int model, float th, u
     est += 2ull * std::min(c->len[x], c->len[y]) * 24;
   }
   dafs_pairhmm_plan plan;
-  int rc = dafs_hipk_pairhmm_plan((uint32_t)np, max1, max2, &plan);
+  int rc = model == DAFS_ALIGN_PROBCONS ? dafs_hipk_pairhmm_plan((uint32_t)np, max1, max2, &plan)
+                                        : dafs_hipk_pairhmm5_plan((uint32_t)np, max1, max2, &plan);
   if (rc) return rc;
   st.rp_total = rp_total;
   if ((rc = c->tasks.upload(tasks.data(), np, c->stream))) return rc;
@@ -97,26 +98,36 @@ extern "C" int dafs_hip_align_posteriors(dafs_hip_ctx* c, int model, float th, u
     if ((rc = st.col.reserve(cap))) return rc;
     if ((rc = st.val.reserve(cap))) return rc;
     if (hip_check(hipMemsetAsync(c->counters.ptr, 0, 4 * sizeof(unsigned long long), c->stream))) return DAFS_HIP_ELAUNCH;
-    dafs_pairhmm3_args a;
-    memset(&a, 0, sizeof a);
-    a.codes = c->codes.ptr;
-    a.tasks = c->tasks.ptr;
-    a.ntasks = (uint32_t)np;
-    a.th = th;
-    a.scratch = c->scratch.ptr;
-    a.queue = (uint32_t*)(c->counters.ptr + 1);
-    a.rp_off = st.rp_off.ptr;
-    a.rowptr_pool = st.rowptr_pool.ptr;
-    a.ent_col = st.col.ptr;
-    a.ent_val = st.val.ptr;
-    a.pool_top = c->counters.ptr;
-    a.pool_cap = cap;
-    a.pair_off = st.pair_off.ptr;
-    a.pair_nnz = st.pair_nnz.ptr;
-    a.sim = c->task_sim.ptr;
-    a.status = (int*)(c->counters.ptr + 2);
-    dafs_hip_pairhmm3_default_model(&a.model);
-    if ((rc = dafs_hipk_pairhmm3_launch(&a, &plan, c->stream))) return rc;
+    auto fill = [&](auto& a) {
+      memset(&a, 0, sizeof a);
+      a.codes = c->codes.ptr;
+      a.tasks = c->tasks.ptr;
+      a.ntasks = (uint32_t)np;
+      a.th = th;
+      a.scratch = c->scratch.ptr;
+      a.queue = (uint32_t*)(c->counters.ptr + 1);
+      a.rp_off = st.rp_off.ptr;
+      a.rowptr_pool = st.rowptr_pool.ptr;
+      a.ent_col = st.col.ptr;
+      a.ent_val = st.val.ptr;
+      a.pool_top = c->counters.ptr;
+      a.pool_cap = cap;
+      a.pair_off = st.pair_off.ptr;
+      a.pair_nnz = st.pair_nnz.ptr;
+      a.sim = c->task_sim.ptr;
+      a.status = (int*)(c->counters.ptr + 2);
+    };
+    if (model == DAFS_ALIGN_PROBCONS) {
+      dafs_pairhmm3_args a;
+      fill(a);
+      dafs_hip_pairhmm3_default_model(&a.model);
+      if ((rc = dafs_hipk_pairhmm3_launch(&a, &plan, c->stream))) return rc;
+    } else {
+      dafs_pairhmm5_args a;
+      fill(a);
+      dafs_hip_pairhmm5_default_model(&a.model);
+      if ((rc = dafs_hipk_pairhmm5_launch(&a, &plan, c->stream))) return rc;
+    }
     unsigned long long host_cnt[4];
     if (hip_check(hipMemcpyAsync(host_cnt, c->counters.ptr, sizeof host_cnt, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
     if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;

@@ -1,0 +1,293 @@
+// dafs_amd/csrc/pairhmm5.hip -- batched CONTRAlign pair-CRF posteriors for gfx950.
+//
+// Replaces, per sequence pair: CONTRALIGN::InferenceEngine<float>::{ComputeForward,
+// ComputeBackward, ComputePosterior} (reference src/contralign/InferenceEngine.ipp:999-1070,
+// 1079-1150, 1279-1317; 5 states MATCH, INS_X, INS_Y, INS2_X, INS2_Y; 24 RNA weights
+// src/contralign/Defaults.ipp:389-419), CONTRAlign::calculate's dense->sparse step
+// (src/align.cpp:87-106), transpose_mp and calculate_similarity_score (src/dafs.cpp:155-167,713-764).
+//
+// Same machine mapping as pairhmm3.hip (G lanes per pair, W columns per lane, rows skewed by
+// lane, boundary column handed to the neighbour lane by shuffle).  Differences:
+//   * the posterior needs, per cell, the five forward terms a_k = Ff[k](i-1,j-1) + ScoreMatch(i,j,k)
+//     and only Fb[MATCH](i,j); the normaliser Z is the FORWARD partition function, known when the
+//     forward sweep ends.  So sweep 1 stores five planes a_k, and sweep 2 (backward) turns them
+//     into the clipped posterior in plane 0 on the fly; sweeps 3-4 are the shared pair_finish.
+//   * the reference's backward pass scatters; every cell here gathers its addends in the order
+//     that scatter delivers them (diagonal source, then the source below, then the source to the
+//     right -- derivation in DESIGN.md), so the log-sum-exp chains round identically.  Row 0 and
+//     column 0 of the backward tables feed nothing the posterior reads and are not computed.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "../../include/dafs_hip.h"
+#include "contra_math.h"
+#include "hip_util.h"
+#include "pair_sweeps.h"
+
+namespace dafs {
+
+enum { cM = 0, cIX = 1, cIY = 2, cI2X = 3, cI2Y = 4 };
+
+template <int G, int W>
+__global__ __launch_bounds__(256) void k_pairhmm5(dafs_pairhmm5_args a, uint32_t slab_steps, uint32_t rp_cap) {
+  constexpr int NG = 64 / G;
+  extern __shared__ uint32_t s_dyn[];
+  __shared__ float s_match[25], s_insert[5], s_single[5], s_pair[25];
+  if (threadIdx.x < 25) { s_match[threadIdx.x] = (&a.model.match[0][0])[threadIdx.x]; s_pair[threadIdx.x] = (&a.model.pair[0][0])[threadIdx.x]; }
+  if (threadIdx.x < 5) { s_insert[threadIdx.x] = a.model.insert[threadIdx.x]; s_single[threadIdx.x] = a.model.single[threadIdx.x]; }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int t = lane % G;
+  const int g = lane / G;
+  const int wave_in_wg = threadIdx.x >> 6;
+  const uint32_t wave = blockIdx.x * 4 + wave_in_wg;
+  const size_t plane = (size_t)slab_steps * W * 64;
+  float* __restrict__ slab = a.scratch + (size_t)wave * plane * 5;
+  uint32_t* __restrict__ s_rowptr = s_dyn + (size_t)(wave_in_wg * NG + g) * rp_cap;
+  const float NI = CONTRA_NEG_INF;
+  const float th = a.th;
+  // transition scores into each state, by source state (InferenceEngine.ipp:139-226)
+  const float pMM = s_pair[cM * 5 + cM], pXM = s_pair[cIX * 5 + cM], pYM = s_pair[cIY * 5 + cM], p2XM = s_pair[cI2X * 5 + cM], p2YM = s_pair[cI2Y * 5 + cM];
+  const float pMX = s_pair[cM * 5 + cIX], pXX = s_pair[cIX * 5 + cIX], pYX = s_pair[cIY * 5 + cIX];
+  const float pMY = s_pair[cM * 5 + cIY], pXY = s_pair[cIX * 5 + cIY], pYY = s_pair[cIY * 5 + cIY];
+  const float pM2X = s_pair[cM * 5 + cI2X], p2X2X = s_pair[cI2X * 5 + cI2X], p2Y2X = s_pair[cI2Y * 5 + cI2X];
+  const float pM2Y = s_pair[cM * 5 + cI2Y], p2X2Y = s_pair[cI2X * 5 + cI2Y], p2Y2Y = s_pair[cI2Y * 5 + cI2Y];
+  const float sgM = s_single[cM], sgX = s_single[cIX], sgY = s_single[cIY], sg2X = s_single[cI2X], sg2Y = s_single[cI2Y];
+
+  for (;;) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(a.queue, (uint32_t)NG);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base >= a.ntasks) break;
+    const uint32_t task = base + g;
+    const bool act = task < a.ntasks;
+    dafs_pair_task tk = {0, 0, 0, 0};
+    if (act) tk = a.tasks[task];
+    const int L1 = act ? (int)tk.len1 : -1;
+    const int L2 = act ? (int)tk.len2 : -1;
+    const uint8_t* __restrict__ s1 = a.codes + tk.off1;
+    const uint8_t* __restrict__ s2 = a.codes + tk.off2;
+    int maxL1 = L1;
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) maxL1 = max(maxL1, __shfl_xor(maxL1, o));
+    const int nsteps = maxL1 + G;
+    const int tlast = (L2 >= 0 ? L2 : 0) / W;
+
+    // y symbols of this lane's columns: cc[c] = y[j], j = t*W + c (CONTRAlign alphabet "ACGU", else 4)
+    int cc[W + 1];
+#pragma unroll
+    for (int c = 0; c <= W; ++c) {
+      const int j = t * W + c;
+      const int code = (j >= 1 && j <= L2) ? (int)s2[j - 1] : 4;
+      cc[c] = code < 4 ? code : 4;
+    }
+
+    // ------------------------------------------------------------------ sweep 1: forward (:999-1070)
+    float Z = NI;
+    {
+      float pM[W], pX[W], pY[W], p2X[W], p2Y[W];  // row i-1 of this lane's columns
+#pragma unroll
+      for (int c = 0; c < W; ++c) pM[c] = pX[c] = pY[c] = p2X[c] = p2Y[c] = NI;
+      float lsM = NI, lsX = NI, lsY = NI, ls2X = NI, ls2Y = NI;  // last column, row of the previous step
+      float dgM = NI, dgX = NI, dgY = NI, dg2X = NI, dg2Y = NI;  // neighbour's last column, one row earlier
+      for (int s = 0; s < nsteps; ++s) {
+        const int i = s - t;
+        const bool rowv = (i >= 0) && (i <= L1);
+        int xi = (rowv && i >= 1) ? (int)s1[i - 1] : 4;
+        xi = xi < 4 ? xi : 4;
+        float rM = shfl_up1<G>(lsM), rX = shfl_up1<G>(lsX), rY = shfl_up1<G>(lsY), r2X = shfl_up1<G>(ls2X), r2Y = shfl_up1<G>(ls2Y);
+        if (t == 0) { rM = NI; rX = NI; rY = NI; r2X = NI; r2Y = NI; }
+        float dM = dgM, dX = dgX, dY = dgY, d2X = dg2X, d2Y = dg2Y;  // (i-1, j-1)
+        float lM = rM, lX = rX, lY = rY, l2X = r2X, l2Y = r2Y;       // (i, j-1)
+        const float insx = 0.0f + s_insert[xi];
+        const float bix = insx + sgX, bi2x = insx + sg2X;            // ScoreInsertX / ScoreInsert2X without the pair term
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          const int j = t * W + c;
+          const bool v = rowv && (j <= L2);
+          const int yj = cc[c];
+          const float insy = 0.0f + s_insert[yj];
+          const float biy = insy + sgY, bi2y = insy + sg2Y;
+          const float bm = (0.0f + s_match[xi * 5 + yj]) + sgM;
+          const bool first = (i == 1 && j == 1);
+          // a_k = Ff[k](i-1,j-1) + ScoreMatch(i,j,k), :446-482 (no pair score on the very first match)
+          const float aM = dM + (bm + (first ? 0.0f : pMM));
+          const float aX = dX + (bm + (first ? 0.0f : pXM));
+          const float aY = dY + (bm + (first ? 0.0f : pYM));
+          const float a2X = d2X + (bm + (first ? 0.0f : p2XM));
+          const float a2Y = d2Y + (bm + (first ? 0.0f : p2YM));
+          float m = contra_lpe(NI, aM);
+          if (!first) { m = contra_lpe(m, aX); m = contra_lpe(m, aY); m = contra_lpe(m, a2X); m = contra_lpe(m, a2Y); }
+          float x = contra_lpe(contra_lpe(contra_lpe(NI, pM[c] + (bix + pMX)), pX[c] + (bix + pXX)), pY[c] + (bix + pYX));
+          float y = contra_lpe(contra_lpe(contra_lpe(NI, lM + (biy + pMY)), lX + (biy + pXY)), lY + (biy + pYY));
+          float x2 = contra_lpe(contra_lpe(contra_lpe(NI, pM[c] + (bi2x + pM2X)), p2X[c] + (bi2x + p2X2X)), p2Y[c] + (bi2x + p2Y2X));
+          float y2 = contra_lpe(contra_lpe(contra_lpe(NI, lM + (bi2y + pM2Y)), l2X + (bi2y + p2X2Y)), l2Y + (bi2y + p2Y2Y));
+          if (i == 0 || j == 0) {  // borders, :1005-1010: only the insert chains run along row 0 / column 0
+            m = NI; x = NI; y = NI; x2 = NI; y2 = NI;
+            if (i == 0 && j == 0) { m = 0.0f; x = 0.0f; y = 0.0f; x2 = 0.0f; y2 = 0.0f; }
+            else if (i == 0) {
+              y = contra_lpe(NI, lY + (biy + (j != 1 ? pYY : 0.0f)));
+              y2 = contra_lpe(NI, l2Y + (bi2y + (j != 1 ? p2Y2Y : 0.0f)));
+            } else {
+              x = contra_lpe(NI, pX[c] + (bix + (i != 1 ? pXX : 0.0f)));
+              x2 = contra_lpe(NI, p2X[c] + (bi2x + (i != 1 ? p2X2X : 0.0f)));
+            }
+          }
+          if (!v) { m = NI; x = NI; y = NI; x2 = NI; y2 = NI; }
+          dM = pM[c]; dX = pX[c]; dY = pY[c]; d2X = p2X[c]; d2Y = p2Y[c];
+          pM[c] = m; pX[c] = x; pY[c] = y; p2X[c] = x2; p2Y[c] = y2;
+          lM = m; lX = x; lY = y; l2X = x2; l2Y = y2;
+          if (v && i >= 1 && j >= 1) {
+            const size_t idx = (size_t)(s * W + c) * 64 + lane;
+            slab[idx] = aM; slab[plane + idx] = aX; slab[2 * plane + idx] = aY; slab[3 * plane + idx] = a2X; slab[4 * plane + idx] = a2Y;
+          }
+          if (v && i == L1 && j == L2) {  // ComputeForwardLogPartitionCoefficient, :1164-1170
+            float z = m;
+            z = contra_lpe(z, x); z = contra_lpe(z, y); z = contra_lpe(z, x2); z = contra_lpe(z, y2);
+            Z = z;
+          }
+        }
+        dgM = rM; dgX = rX; dgY = rY; dg2X = r2X; dg2Y = r2Y;
+        lsM = pM[W - 1]; lsX = pX[W - 1]; lsY = pY[W - 1]; ls2X = p2X[W - 1]; ls2Y = p2Y[W - 1];
+      }
+    }
+    Z = __shfl(Z, g * G + tlast);
+
+    // ------------------------------------------------------------------ sweep 2: backward (:1079-1150) + posterior (:1279-1317)
+    {
+      float pM[W], pX[W], p2X[W];      // row a+1 of this lane's columns: Fb[M], Fb[IX], Fb[I2X]
+#pragma unroll
+      for (int c = 0; c < W; ++c) pM[c] = pX[c] = p2X[c] = NI;
+      float fsM = NI, fsY = NI, fs2Y = NI;  // this lane's first column, row of the previous step
+      float dgM = NI;                       // right neighbour's first column, one row later
+      for (int s = 0; s < nsteps; ++s) {
+        const int i = L1 - s + (G - 1 - t);
+        const bool rowv = (i >= 1) && (i <= L1);
+        const int sf = i + t;
+        int xn = (rowv && i < L1) ? (int)s1[i] : 4;  // x[i+1]
+        xn = xn < 4 ? xn : 4;
+        float rM = shfl_down1<G>(fsM), rY = shfl_down1<G>(fsY), r2Y = shfl_down1<G>(fs2Y);
+        if (t == G - 1) { rM = NI; rY = NI; r2Y = NI; }
+        float dM = dgM;              // Fb[M](i+1, j+1)
+        float gY = rY, g2Y = r2Y;    // Fb[IY](i, j+1), Fb[I2Y](i, j+1)
+        const float insx = 0.0f + s_insert[xn];
+        const float bix = insx + sgX, bi2x = insx + sg2X;
+        float ak[5][W];
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          const int j = t * W + c;
+          const bool v = rowv && j >= 1 && j <= L2;
+          const size_t idx = (size_t)(sf * W + c) * 64 + lane;
+#pragma unroll
+          for (int k = 0; k < 5; ++k) ak[k][c] = v ? slab[k * plane + idx] : 0.0f;
+        }
+#pragma unroll
+        for (int c = W - 1; c >= 0; --c) {
+          const int j = t * W + c;
+          const bool v = rowv && j >= 1 && j <= L2;
+          const int yn = cc[c + 1];  // y[j+1]
+          const float insy = 0.0f + s_insert[yn];
+          const float biy = insy + sgY, bi2y = insy + sg2Y;
+          const float bm = (0.0f + s_match[xn * 5 + yn]) + sgM;
+          // sources in delivery order: (i+1,j+1) match block, (i+1,j) insert-X blocks, (i,j+1) insert-Y blocks
+          float bM = NI, bX = NI, bY = NI, b2X = NI, b2Y = NI;
+          bM = contra_lpe(bM, dM + (bm + pMM));
+          bX = contra_lpe(bX, dM + (bm + pXM));
+          bY = contra_lpe(bY, dM + (bm + pYM));
+          b2X = contra_lpe(b2X, dM + (bm + p2XM));
+          b2Y = contra_lpe(b2Y, dM + (bm + p2YM));
+          bM = contra_lpe(bM, pX[c] + (bix + pMX));
+          bX = contra_lpe(bX, pX[c] + (bix + pXX));
+          bY = contra_lpe(bY, pX[c] + (bix + pYX));
+          bM = contra_lpe(bM, p2X[c] + (bi2x + pM2X));
+          b2X = contra_lpe(b2X, p2X[c] + (bi2x + p2X2X));
+          b2Y = contra_lpe(b2Y, p2X[c] + (bi2x + p2Y2X));
+          bM = contra_lpe(bM, gY + (biy + pMY));
+          bX = contra_lpe(bX, gY + (biy + pXY));
+          bY = contra_lpe(bY, gY + (biy + pYY));
+          bM = contra_lpe(bM, g2Y + (bi2y + pM2Y));
+          b2X = contra_lpe(b2X, g2Y + (bi2y + p2X2Y));
+          b2Y = contra_lpe(b2Y, g2Y + (bi2y + p2Y2Y));
+          if (i == L1 && j == L2) { bM = 0.0f; bX = 0.0f; bY = 0.0f; b2X = 0.0f; b2Y = 0.0f; }  // :1084
+          if (!v) { bM = NI; bX = NI; bY = NI; b2X = NI; b2Y = NI; }
+          dM = pM[c];
+          pM[c] = bM; pX[c] = bX; p2X[c] = b2X;
+          gY = bY; g2Y = b2Y;
+          if (v) {  // ComputePosterior :1289-1305 + Clip :1308-1315
+            float p = 0.0f;
+            p += contra_exp(ak[0][c] + bM - Z);
+            if (i > 1 || j > 1) {
+              p += contra_exp(ak[1][c] + bM - Z);
+              p += contra_exp(ak[2][c] + bM - Z);
+              p += contra_exp(ak[3][c] + bM - Z);
+              p += contra_exp(ak[4][c] + bM - Z);
+            }
+            const float mx = p < 0.0f ? 0.0f : p;
+            slab[(size_t)(sf * W + c) * 64 + lane] = (1.0f < mx) ? 1.0f : mx;
+          }
+          if (c == 0) { fsY = bY; fs2Y = b2Y; }
+        }
+        dgM = rM;
+        fsM = pM[0];
+      }
+    }
+    // row 0 / column 0 of plane 0 were never written: pair_finish ignores them (inner cells only)
+    pair_finish<G, W>(a, slab, s_rowptr, lane, t, g, L1, L2, nsteps, tlast, act, task, th, [](float sv) { return sv; });
+  }
+}
+
+typedef void (*pairhmm5_fn)(dafs_pairhmm5_args, uint32_t, uint32_t);
+struct variant5 { int G, W; pairhmm5_fn fn; };
+#define V(G, W) {G, W, k_pairhmm5<G, W>}
+static const variant5 k_variants5[] = {
+    V(16, 2), V(16, 3), V(16, 4), V(16, 5), V(16, 6), V(16, 8), V(16, 10), V(16, 11), V(16, 12),
+    V(32, 2), V(32, 3), V(32, 4), V(32, 5), V(32, 6), V(32, 8), V(32, 10), V(32, 12),
+    V(64, 1), V(64, 2), V(64, 3), V(64, 4), V(64, 5), V(64, 6), V(64, 8), V(64, 10), V(64, 12), V(64, 16),
+};
+#undef V
+static const uint32_t kMaxWaves5 = 256 * 8;
+
+}  // namespace dafs
+
+using namespace dafs;
+
+extern "C" int dafs_hipk_pairhmm5_plan(uint32_t ntasks, uint32_t max_len1, uint32_t max_len2, dafs_pairhmm_plan* plan) {
+  if (!plan || ntasks == 0 || max_len1 == 0 || max_len2 == 0) return DAFS_HIP_EINVAL;
+  const variant5* best = nullptr;
+  double best_cost = 0;
+  const char* force = getenv("DAFS_HIP_FORCE_GROUP");
+  const int force_g = force ? atoi(force) : 0;
+  for (const variant5& v : k_variants5) {
+    if ((uint64_t)v.G * v.W < (uint64_t)max_len2 + 1) continue;
+    if (force_g && v.G != force_g) continue;
+    const uint64_t waves = ((uint64_t)ntasks + (64 / v.G) - 1) / (64 / v.G);
+    const uint64_t rounds = (waves + kMaxWaves5 - 1) / kMaxWaves5;
+    const double cost = (double)(max_len1 + v.G) * v.W * (double)rounds;
+    if (!best || cost < best_cost) { best = &v; best_cost = cost; }
+  }
+  if (!best) return DAFS_HIP_ETOOLONG;
+  const uint64_t waves = ((uint64_t)ntasks + (64 / best->G) - 1) / (64 / best->G);
+  plan->group = best->G;
+  plan->width = best->W;
+  uint32_t nw = (uint32_t)(waves < kMaxWaves5 ? waves : kMaxWaves5);
+  nw = (nw + 3) & ~3u;
+  plan->nwaves = nw;
+  plan->slab_steps = max_len1 + best->G;
+  plan->scratch_bytes = (uint64_t)nw * plan->slab_steps * best->W * 64 * sizeof(float) * 5;  // five planes
+  return DAFS_HIP_OK;
+}
+
+extern "C" int dafs_hipk_pairhmm5_launch(const dafs_pairhmm5_args* args, const dafs_pairhmm_plan* plan, void* hip_stream) {
+  if (!args || !plan) return DAFS_HIP_EINVAL;
+  if (args->ntasks == 0) return DAFS_HIP_OK;
+  const variant5* v = nullptr;
+  for (const variant5& c : k_variants5)
+    if (c.G == (int)plan->group && c.W == (int)plan->width) v = &c;
+  if (!v || plan->nwaves % 4) return DAFS_HIP_EINVAL;
+  const uint32_t rp_cap = plan->slab_steps - plan->group + 1;
+  const size_t lds = (size_t)4 * (64 / v->G) * rp_cap * sizeof(uint32_t);
+  if (lds > 60 * 1024) return DAFS_HIP_ETOOLONG;
+  hipLaunchKernelGGL(v->fn, dim3(plan->nwaves / 4), dim3(256), lds, (hipStream_t)hip_stream, *args, plan->slab_steps, rp_cap);
+  return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
+}

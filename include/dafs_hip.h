@@ -111,9 +111,47 @@ void dafs_hip_pairhmm3_default_model(dafs_pairhmm3_model* m);
 uint8_t dafs_hip_residue_code(char c);
 
 /* ------------------------------------------------------------------------------------------
+ * L0: pair-CRF posterior kernel (CONTRAlign 5-state model).
+ * Replaces, per pair: CONTRALIGN::CONTRAlign<float>::ComputePosterior
+ * (src/contralign/wrapper.cpp:81-97) + CONTRAlign::calculate's dense->sparse step
+ * (src/align.cpp:87-106) + transpose_mp + calculate_similarity_score.  Same argument layout and
+ * outputs as the ProbCons kernel; the scratch holds five planes (dafs_hipk_pairhmm5_plan).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  float match[5][5]; /* symbol 0..3 = A C G U, 4 = anything else (scores 0), Defaults.ipp:393-402 */
+  float insert[5];   /* Defaults.ipp:403-406 */
+  float single[5];   /* per state MATCH, INS_X, INS_Y, INS2_X, INS2_Y, Defaults.ipp:407-409 */
+  float pair[5][5];  /* transition [from][to], Defaults.ipp:410-416 */
+} dafs_pairhmm5_model;
+
+typedef struct {
+  const uint8_t* codes;
+  const dafs_pair_task* tasks;
+  uint32_t ntasks;
+  float th;
+  float* scratch;
+  uint32_t* queue;
+  const uint64_t* rp_off;
+  uint32_t* rowptr_pool;
+  uint32_t* ent_col;
+  float* ent_val;
+  unsigned long long* pool_top;
+  uint64_t pool_cap;
+  uint64_t* pair_off;
+  uint32_t* pair_nnz;
+  float* sim;
+  int* status;
+  dafs_pairhmm5_model model;
+} dafs_pairhmm5_args;
+
+int dafs_hipk_pairhmm5_plan(uint32_t ntasks, uint32_t max_len1, uint32_t max_len2, dafs_pairhmm_plan* plan);
+int dafs_hipk_pairhmm5_launch(const dafs_pairhmm5_args* args, const dafs_pairhmm_plan* plan, void* hip_stream);
+void dafs_hip_pairhmm5_default_model(dafs_pairhmm5_model* m);
+
+/* ------------------------------------------------------------------------------------------
  * L1: batch alignment-posterior plugin.
  * Replaces Align::Model::calculate(const vector<Fasta>&, vector<vector<MP>>&)
- * (src/align.cpp:35-52) for -a ProbCons, plus the transposes (src/dafs.cpp:1797-1799) and
+ * (src/align.cpp:35-52) for -a ProbCons / -a CONTRAlign, plus the transposes (src/dafs.cpp:1797-1799) and
  * sim_ (src/dafs.cpp:1813-1819), for the pair-index shard [pair_begin, pair_end) of the
  * row-major (i<j) pair enumeration (pair_end = 0 means all pairs).
  * ---------------------------------------------------------------------------------------- */

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 EX = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _check_set(oracle, seqs, th=0.01, force_group=None):
+def _check_set(oracle, seqs, th=0.01, force_group=None, model=0):
     from dafs_amd import capi
     if force_group:
         os.environ["DAFS_HIP_FORCE_GROUP"] = str(force_group)
@@ -21,7 +21,7 @@ def _check_set(oracle, seqs, th=0.01, force_group=None):
     ctx = capi.Context(0)
     try:
         ctx.set_sequences(seqs)
-        res = ctx.align_posteriors(capi.ALIGN_PROBCONS, th)
+        res = ctx.align_posteriors(model, th)
     finally:
         ctx.close()
         os.environ.pop("DAFS_HIP_FORCE_GROUP", None)
@@ -31,7 +31,7 @@ def _check_set(oracle, seqs, th=0.01, force_group=None):
     for i in range(n):
         for j in range(i + 1, n):
             assert res.pair_x[p] == i and res.pair_y[p] == j
-            rp, col, val = oracle.align_calculate(seqs[i], seqs[j], th)
+            rp, col, val = oracle.align_calculate(seqs[i], seqs[j], th, model)
             grp, gcol, gval = res.csr(p)
             assert np.array_equal(grp, rp), (i, j, "rowptr")
             assert np.array_equal(gcol, col), (i, j, "col")
@@ -95,3 +95,60 @@ def test_pair_shard(oracle):
             a, b = part.csr(k, tr), full.csr(10 + k, tr)
             assert all(np.array_equal(x, y) for x, y in zip(a, b))
         assert part.sim[k] == full.sim[10 + k]
+
+
+# ---- CONTRAlign (rows a8, a9): same contract, 5-state model ----
+def test_contralign_rf00005_all_pairs(oracle):
+    seqs = [s for _, s in oracle.fasta(os.path.join(EX, "RF00005_0.fa"))]
+    _check_set(oracle, seqs, model=1)
+
+
+@pytest.mark.parametrize("group", [16, 32, 64])
+def test_contralign_every_group(oracle, group):
+    seqs = [s for _, s in synth.random_set(7, 60, seed=7)]
+    _check_set(oracle, seqs, force_group=group, model=1)
+
+
+@pytest.mark.parametrize("n,length,seed", [(6, 150, 12345), (4, 300, 5)])
+def test_contralign_synthetic_sets(oracle, n, length, seed):
+    seqs = [s for _, s in synth.random_set(n, length, seed=seed)]
+    _check_set(oracle, seqs, model=1)
+
+
+def test_contralign_ragged_and_odd_residues(oracle):
+    seqs = ["A", "CG", "acgu", "GGGAAACCC", "NNTTXXzA", "ACGUACGUACGUACGUACGUACGUACGUACGUACGU", "u" * 17]
+    for g in (None, 16):
+        _check_set(oracle, seqs, force_group=g, model=1)
+    _check_set(oracle, seqs, th=0.0, model=1)
+
+
+def test_contralign_golden_rows():
+    """the committed reference-generated rows, straight against the device"""
+    from dafs_amd import capi
+    z = np.load(os.path.join(EX, "contralign_mp.npz"))
+    ctx = capi.Context(0)
+    for k in (0, 7, 44, 45, 50, 54, 60):
+        s1, s2 = str(z["seq1"][k]), str(z["seq2"][k])
+        ctx.set_sequences([s1, s2])
+        res = ctx.align_posteriors(capi.ALIGN_CONTRALIGN, float(z["th"]))
+        rp, col, val = res.csr(0)
+        r0, r1, e0, e1 = z["rp_off"][k], z["rp_off"][k + 1], z["ent_off"][k], z["ent_off"][k + 1]
+        assert np.array_equal(rp, z["rowptr"][r0:r1]) and np.array_equal(col, z["col"][e0:e1])
+        assert val.tobytes() == z["val"][e0:e1].tobytes()
+    ctx.close()
+
+
+def test_whole_run_contralign(oracle):
+    import test_oracle_cpu as t
+    from dafs_amd import capi, pipeline
+    ka = t.known()
+    recs = oracle.fasta(os.path.join(EX, "RF00005_0.fa"))
+    names, seqs = [n for n, _ in recs], [s for _, s in recs]
+    got = pipeline.run(names, seqs, align_model=capi.ALIGN_CONTRALIGN)
+    assert got.tree_line == ka["rf00005.contralign.tree"]
+    assert len(got.rows[0]) == int(ka["rf00005.contralign.contrafold.columns"])
+    assert got.rows[0] == ka["rf00005.contralign.contrafold.first_row"]
+    pl = oracle.pipeline(names, seqs, oracle.params(fold_model=0, align_model=1))
+    pl.phase1(); pl.phase2()
+    assert got.output == pl.output()
+    pl.close()
