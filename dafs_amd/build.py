@@ -20,7 +20,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++
 
 
 def sources():
-    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")) and not f.startswith("cli_"))
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
 def _stale(src, obj):
@@ -59,5 +59,30 @@ def build(force=False):
     return OUT
 
 
+HOST = os.path.join(CSRC, "host")
+CLI = os.path.join(HERE, "dafs")
+SELFTEST = os.path.join(HERE, "plugin_selftest")
+
+
+def build_cli(force=False):
+    """The C++ host side: the `dafs` command line and the plugin self-test, linked against libdafs_hip.so."""
+    cxx = os.environ.get("CXX", "g++")
+    common = [os.path.join(HOST, "fasta.cpp")]
+    targets = ((CLI, common + [os.path.join(HOST, "cli_main.cpp")]),
+               (SELFTEST, common + [os.path.join(HOST, "plugins.cpp"), os.path.join(HOST, "plugin_selftest.cpp")]))
+    deps = [os.path.join(HOST, f) for f in os.listdir(HOST)] + [os.path.join(HERE, "..", "include", "dafs_hip.h"), OUT]
+    for out, srcs in targets:
+        if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+            continue
+        cmd = [cxx, "-std=c++17", "-O2", "-Wall", "-o", out] + srcs + ["-L" + HERE, "-ldafs_hip", "-Wl,-rpath,$ORIGIN"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("host build failed:\n" + r.stderr)
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+    return CLI
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_cli(force="--force" in sys.argv))
