@@ -38,15 +38,13 @@ BASE_N, BASE_L = 128, 150
 
 
 def build_shard(n_seq, length, world, rank, seed=12345):
-    from dafs_amd import synth
+    from dafs_amd import dist as ddist, synth
     recs = synth.random_set(n_seq, length, seed=seed)
+    names = [n for n, _ in recs]
     seqs = [s for _, s in recs]
     lens = np.array([len(s) for s in seqs], dtype=np.int64)
-    ii, jj = np.triu_indices(n_seq, k=1)
-    cost = lens[ii] * lens[jj]
-    order = np.argsort(-cost, kind="stable")  # longest first; dealt round-robin to the ranks
-    mine = order[rank::world]
-    return seqs, lens, ii[mine], jj[mine], len(order)
+    px, py, total = ddist.shard_pairs(lens, world, rank)
+    return names, seqs, lens, px, py, total
 
 
 def cpu_baseline(seqs, px, py, th, budget_s=15.0):
@@ -89,6 +87,7 @@ def main():
     ap.add_argument("--length", type=int, default=BASE_L)
     ap.add_argument("--th", type=float, default=0.01)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end wall-clock leg")
     args = ap.parse_args()
 
     import torch
@@ -109,7 +108,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     n_seq = args.n_seq or int(round(BASE_N * math.sqrt(world)))
-    seqs, lens, px, py, total_pairs = build_shard(n_seq, args.length, world, rank)
+    names, seqs, lens, px, py, total_pairs = build_shard(n_seq, args.length, world, rank)
     np_local = len(px)
 
     # ---- device-resident inputs (torch = allocator + stream only) ----
@@ -149,15 +148,10 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
+    ex = None
     if world > 1:
-        # fixed-stride all-gather slabs (max over ranks, exchanged once up front)
-        sizes = torch.tensor([np_local, rp_total, pool_cap], dtype=torch.int64, device=dev)
-        dist.all_reduce(sizes, op=dist.ReduceOp.MAX)
-        mx_pairs, mx_rp, mx_pool = [int(v) for v in sizes.tolist()]
-        g_meta = torch.empty(world * mx_pairs * 4, dtype=torch.int32, device=dev)   # nnz, sim bits, off lo/hi
-        g_rowptr = torch.empty(world * mx_rp, dtype=torch.int32, device=dev)
-        s_meta = torch.zeros(mx_pairs * 4, dtype=torch.int32, device=dev)
-        s_rowptr = torch.zeros(mx_rp, dtype=torch.int32, device=dev)
+        from dafs_amd import dist as ddist
+        ex = ddist.ShardExchange(dist, dev, world, np_local, rp_total, pool_cap)
 
     def step(k=None):
         d_counters.zero_()
@@ -166,22 +160,10 @@ def main():
         capi.check(capi.pairhmm3_launch(C.byref(a), C.byref(plan), C.c_void_p(stream.cuda_stream)))
         if k is not None:
             ev1[k].record(stream)
-        if world > 1:
+        if ex is not None:
             # the one exchange of the path: every rank ends up with every pair's sparse posteriors
             used = int(d_counters[0].item())  # entries this rank produced (host sync: payload size)
-            mx = torch.tensor([used], dtype=torch.int64, device=dev)
-            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-            m = int(mx.item())
-            s_meta.view(mx_pairs, 4)[:np_local, 0] = d_pair_nnz
-            s_meta.view(mx_pairs, 4)[:np_local, 1] = d_sim.view(torch.int32)
-            s_meta.view(mx_pairs, 4)[:np_local, 2:4] = d_pair_off.view(torch.int32).view(np_local, 2)
-            s_rowptr[:rp_total] = d_rowptr
-            g_col = torch.empty(world * m, dtype=torch.int32, device=dev)
-            g_val = torch.empty(world * m, dtype=torch.float32, device=dev)
-            dist.all_gather_into_tensor(g_meta, s_meta)
-            dist.all_gather_into_tensor(g_rowptr, s_rowptr)
-            dist.all_gather_into_tensor(g_col, d_col[:m])
-            dist.all_gather_into_tensor(g_val, d_val[:m])
+            ex.exchange(d_pair_nnz, d_sim, d_pair_off, d_rowptr, d_col, d_val, used)
 
     for _ in range(args.warmup):
         step()
@@ -213,6 +195,23 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(seqs, px, py, args.th)
 
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_e2e:
+        # BASELINE.json's second quantity: end-to-end wall-clock of the whole run (fold, pair posteriors,
+        # consistency, tree, progressive DD, final structure) on the same set; not part of `value`.
+        from dafs_amd import pipeline
+        ctx = capi.Context(local_rank)
+        pipeline.run(names[:8], seqs[:8], ctx=ctx)  # warm-up (allocations, code objects)
+        t0 = time.perf_counter()
+        res = pipeline.run(names, seqs, ctx=ctx)
+        wall = time.perf_counter() - t0
+        its = [v[0] for v in res.dd_log.values()]
+        e2e = {"wall_s": wall, "flags": "-a ProbCons -s CONTRAfold --no-alifold (defaults otherwise)",
+               "phases_s": {k: round(v, 4) for k, v in res.seconds.items()},
+               "dd_iterations_total": int(np.sum(its)), "dd_iterations_max": int(np.max(its)), "tree_levels": res.levels,
+               "columns": len(res.rows[0])}
+        ctx.close()
+
     if rank == 0:
         out = {
             "metric": "seq-pairs/sec (all-pairs ProbCons pair-HMM posteriors + sparse rows + sim)",
@@ -232,6 +231,8 @@ def main():
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
         }
+        if e2e is not None:
+            out["end_to_end"] = e2e
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

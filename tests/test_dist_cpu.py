@@ -1,0 +1,123 @@
+"""CPU test of the N>1 path (world_size 2, gloo): pair sharding + the single all-gather.  The shard
+outputs are produced by the oracle in the exact layout the pair kernel writes (including an
+arbitrary, rank-dependent pool order, as the device-side bump allocator gives), gathered with
+dafs_amd.dist.ShardExchange, and every pair is checked on every rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import oracle_lib
+    from dafs_amd import dist as dd, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = oracle_lib.load_oracle()
+        seqs = [s for _, s in synth.random_set(7, 30, seed=77)]
+        lens = [len(s) for s in seqs]
+        px, py, total = dd.shard_pairs(lens, world, rank)
+        assert total == 21
+        # oracle results laid out like k_pairhmm3's outputs
+        rows, nnz, sims = [], [], []
+        for x, y in zip(px, py):
+            rp, col, val = orc.align_calculate(seqs[x], seqs[y], 0.01, 0)
+            r = np.repeat(np.arange(lens[x], dtype=np.uint32), np.diff(rp))
+            o = np.lexsort((r, col))
+            trp = np.concatenate([[0], np.cumsum(np.bincount(col, minlength=lens[y]))]).astype(np.uint32)
+            rows.append((rp, col, val, trp, r[o], val[o]))
+            nnz.append(len(col))
+            sims.append(orc.similarity(rp, col, val, lens[x], lens[y]))
+        rng = np.random.default_rng(100 + rank)         # arbitrary pool order (bump allocator)
+        order = rng.permutation(len(px))
+        off = np.zeros(len(px), np.int64)
+        top = 0
+        for k in order:
+            off[k] = top
+            top += 2 * nnz[k]
+        cap = top + 17
+        col = np.zeros(cap, np.uint32); val = np.zeros(cap, np.float32)
+        rowptr = []
+        for k, (rp, c, v, trp, tc, tv) in enumerate(rows):
+            col[off[k]:off[k] + nnz[k]] = c; val[off[k]:off[k] + nnz[k]] = v
+            col[off[k] + nnz[k]:off[k] + 2 * nnz[k]] = tc; val[off[k] + nnz[k]:off[k] + 2 * nnz[k]] = tv
+            rowptr += [rp, trp]
+        rowptr = np.concatenate(rowptr).astype(np.uint32)
+        dev = torch.device("cpu")
+        ex = dd.ShardExchange(dist, dev, world, len(px), len(rowptr), cap)
+        ex.exchange(torch.tensor(nnz, dtype=torch.int32), torch.tensor(np.array(sims, np.float32)), torch.from_numpy(off),
+                    torch.from_numpy(rowptr.view(np.int32)), torch.from_numpy(col.view(np.int32)), torch.from_numpy(val), top)
+        g = ex.gathered(lens)
+        n = len(seqs)
+        seen = 0
+        for x in range(n):
+            for y in range(x + 1, n):
+                rp, c, v = orc.align_calculate(seqs[x], seqs[y], 0.01, 0)
+                grp, gc, gv = g.csr(x, y)
+                assert np.array_equal(grp, rp) and np.array_equal(gc, c) and gv.tobytes() == v.tobytes(), (x, y)
+                trp, tc, tv = g.csr(y, x)
+                r = np.repeat(np.arange(lens[x], dtype=np.uint32), np.diff(rp))
+                o = np.lexsort((r, c))
+                assert np.array_equal(tc, r[o]) and tv.tobytes() == v[o].tobytes(), (y, x)
+                assert np.float32(g.sim(x, y)).tobytes() == np.float32(orc.similarity(rp, c, v, lens[x], lens[y])).tobytes()
+                seen += 1
+        assert seen == total
+        sm = g.sim_matrix()
+        assert np.array_equal(sm, sm.T) and np.all(np.diag(sm) == 1)
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_partition_is_exact():
+    sys.path.insert(0, ROOT)
+    from dafs_amd import dist as dd
+    lens = [150, 141, 160, 152, 149, 158, 144, 151, 80]
+    for world in (1, 2, 3, 4, 8):
+        seen = set()
+        sizes = []
+        for r in range(world):
+            px, py, total = dd.shard_pairs(lens, world, r)
+            assert total == 36
+            cost = np.array(lens)[px] * np.array(lens)[py]
+            assert np.all(np.diff(cost) <= 0)            # longest first
+            for x, y in zip(px, py):
+                assert x < y and (x, y) not in seen
+                seen.add((int(x), int(y)))
+            sizes.append(len(px))
+        assert len(seen) == 36 and max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_all_gather_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
