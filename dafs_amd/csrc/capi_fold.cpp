@@ -123,7 +123,9 @@ int run_job(dafs_hip_ctx* c, const fold_job& job, const uint8_t* d_codes, const 
   B.post = c->cf_post.ptr;
   B.logz = c->cf_logz.ptr;
   *out = B;
-  return contrafold_launch(B, (uint32_t)job.seqs.size(), c->stream);
+  uint32_t max_len = 0;
+  for (const cf_seq& q : job.seqs) max_len = std::max(max_len, q.len);
+  return contrafold_launch(B, (uint32_t)job.seqs.size(), max_len, c->stream);
 }
 
 }  // namespace

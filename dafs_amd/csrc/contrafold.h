@@ -27,7 +27,7 @@ struct cf_seq {
   uint32_t code_off;       // into cf_batch.codes
   uint32_t has_constraint;
   uint32_t cons_off;       // into cf_batch.cons (len+1 ints, index = position)
-  uint64_t iws_off;        // into cf_batch.iws: 4*(len+2) ints
+  uint64_t iws_off;        // unused (integer tables live in LDS)
   uint64_t fws_off;        // into cf_batch.fws: 7*S + 2*(len+1) floats, S = (len+1)(len+2)/2
   uint64_t post_off;       // into cf_batch.post: S floats
 };
@@ -44,7 +44,7 @@ struct cf_batch {
 };
 
 void contrafold_default_params(cf_params* p);  // host: tables + caches
-int contrafold_launch(const cf_batch& B, uint32_t nseq, hipStream_t st);
+int contrafold_launch(const cf_batch& B, uint32_t nseq, uint32_t max_len, hipStream_t st);
 int bp_compact_launch(const cf_batch& B, uint32_t nseq, float th, const uint64_t* rp_off, uint32_t* out_rowptr, uint32_t* out_col,
                       float* out_val, uint64_t* out_off, uint32_t* out_nnz, unsigned long long* pool_top, uint64_t pool_cap, int* status,
                       hipStream_t st);

@@ -236,8 +236,10 @@ __global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B) {
   const cf_seq sq = B.seqs[x];
   const int L = (int)sq.len;
   const int tid = threadIdx.x, nt = blockDim.x;
-  int* ws_i = B.iws + sq.iws_off;
-  int* s = ws_i;                 // L+2
+  // symbols, constraint map, prefix counts and row offsets are read in every inner-loop test:
+  // keep them in LDS (4*(L+2) ints)
+  extern __shared__ int s_ints[];
+  int* s = s_ints;               // L+2
   int* map = s + (L + 2);        // L+2
   int* cum = map + (L + 2);      // L+2
   int* off = cum + (L + 2);      // L+2
@@ -374,9 +376,11 @@ __global__ __launch_bounds__(256) void k_bp_compact(cf_batch B, float th, const 
   }
 }
 
-int contrafold_launch(const cf_batch& B, uint32_t nseq, hipStream_t st) {
+int contrafold_launch(const cf_batch& B, uint32_t nseq, uint32_t max_len, hipStream_t st) {
   if (!nseq) return DAFS_HIP_OK;
-  hipLaunchKernelGGL(k_contrafold, dim3(nseq), dim3(CF_THREADS), 0, st, B);
+  const size_t lds = 4 * ((size_t)max_len + 2) * sizeof(int);
+  if (lds > 48 * 1024) return DAFS_HIP_ETOOLONG;
+  hipLaunchKernelGGL(k_contrafold, dim3(nseq), dim3(CF_THREADS), lds, st, B);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 

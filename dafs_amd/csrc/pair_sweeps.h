@@ -15,12 +15,36 @@
 
 namespace dafs {
 
+// Neighbour exchange inside a group of G lanes: value of lane t-1 (shift_up1) or t+1 (shift_down1),
+// `fill` at the group boundary.  For G = 16 a group is one DPP row, so the move is a single
+// row_shr:1 / row_shl:1 VALU instruction with the boundary fill for free.
 template <int G>
-__device__ __forceinline__ float shfl_up1(float v) { return __shfl_up(v, 1, G); }
+__device__ __forceinline__ float shift_up1(float v, float fill, int t) {
+  if constexpr (G == 16) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x111, 0xF, 0xF, false));
+  } else {
+    const float r = __shfl_up(v, 1, G);
+    return t == 0 ? fill : r;
+  }
+}
 template <int G>
-__device__ __forceinline__ int shfl_up1(int v) { return __shfl_up(v, 1, G); }
+__device__ __forceinline__ int shift_up1(int v, int fill, int t) {
+  if constexpr (G == 16) {
+    return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xF, 0xF, false);
+  } else {
+    const int r = __shfl_up(v, 1, G);
+    return t == 0 ? fill : r;
+  }
+}
 template <int G>
-__device__ __forceinline__ float shfl_down1(float v) { return __shfl_down(v, 1, G); }
+__device__ __forceinline__ float shift_down1(float v, float fill, int t) {
+  if constexpr (G == 16) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x101, 0xF, 0xF, false));
+  } else {
+    const float r = __shfl_down(v, 1, G);
+    return t == G - 1 ? fill : r;
+  }
+}
 
 template <int G, int W, class Args, class Post>
 __device__ __forceinline__ void pair_finish(const Args& a, float* __restrict__ slab, uint32_t* __restrict__ s_rowptr, int lane, int t, int g,
@@ -41,16 +65,14 @@ __device__ __forceinline__ void pair_finish(const Args& a, float* __restrict__ s
     for (int s = 0; s < nsteps; ++s) {
       const int i = s - t;
       const bool rowv = (i >= 0) && (i <= L1);
-      float rdp = shfl_up1<G>(lastdp);
-      int rtr = shfl_up1<G>(lasttr), rcnt = shfl_up1<G>(lastcnt);
-      if (t == 0) { rdp = 0.0f; rtr = 0; rcnt = 0; }
+      const float rdp = shift_up1<G>(lastdp, 0.0f, t);
+      const int rtr = shift_up1<G>(lasttr, 0, t), rcnt = shift_up1<G>(lastcnt, 0, t);
       float ddp = dgdp, ldp = rdp;
       int dtr = dgtr, ltr = rtr, run = rcnt;
       float sv[W];
 #pragma unroll
       for (int c = 0; c < W; ++c) {
-        const int j = t * W + c;
-        sv[c] = (rowv && j <= L2) ? slab[(size_t)(s * W + c) * 64 + lane] : 0.0f;
+        sv[c] = slab[(size_t)(s * W + c) * 64 + lane];  // private slot: unguarded (cells outside the grid are ignored below)
       }
 #pragma unroll
       for (int c = 0; c < W; ++c) {
@@ -60,7 +82,7 @@ __device__ __forceinline__ void pair_finish(const Args& a, float* __restrict__ s
         // the model's posterior; wrapper (>= th keeps) then adapter (> th keeps): align.cpp:69-78
         const float p = post(sv[c]);
         const bool entry = inner && (p >= th) && (p > th);
-        if (v) slab[(size_t)(s * W + c) * 64 + lane] = entry ? p : 0.0f;
+        slab[(size_t)(s * W + c) * 64 + lane] = entry ? p : 0.0f;
         // calculate_similarity_score, dafs.cpp:720-760
         const float udp = pdp[c];
         const int utr = ptr[c];
@@ -144,15 +166,12 @@ __device__ __forceinline__ void pair_finish(const Args& a, float* __restrict__ s
     for (int s = 0; s < nsteps; ++s) {
       const int i = s - t;
       const bool rowv = (i >= 0) && (i <= L1);
-      int rcnt = shfl_up1<G>(lastcnt);
-      if (t == 0) rcnt = 0;
-      int run = rcnt;
+      int run = shift_up1<G>(lastcnt, 0, t);
       const uint32_t rowbase = (rowv && i >= 1) ? s_rowptr[i - 1] : 0;
       float pv[W];
 #pragma unroll
       for (int c = 0; c < W; ++c) {
-        const int j = t * W + c;
-        pv[c] = (rowv && j <= L2) ? slab[(size_t)(s * W + c) * 64 + lane] : 0.0f;
+        pv[c] = slab[(size_t)(s * W + c) * 64 + lane];  // sweep 3 left 0 in every non-entry slot
       }
 #pragma unroll
       for (int c = 0; c < W; ++c) {

@@ -35,12 +35,14 @@
 
 namespace dafs {
 
-template <int G, int W>
+template <int G, int W, bool LUT>
 __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t slab_steps, uint32_t rp_cap) {
   constexpr int NG = 64 / G;  // pairs per wavefront
   extern __shared__ uint32_t s_dyn[];  // per (wave, group): rp_cap row pointers
   __shared__ float s_match[56];
   __shared__ float s_ins[8];
+  __shared__ pc_tables s_tab;
+  pc_tables_init(&s_tab, threadIdx.x);
   if (threadIdx.x < 56) s_match[threadIdx.x] = (&a.model.match[0][0])[threadIdx.x];
   if (threadIdx.x < 8) s_ins[threadIdx.x] = a.model.ins[threadIdx.x];
   __syncthreads();
@@ -94,8 +96,11 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
     const float fX10 = i1 + s_ins[c1first];
     const float fY01 = i2 + s_ins[c2first];
 
+    // Cells outside the grid need no masking: every table starts at LOG_ZERO and the recursions map
+    // LOG_ZERO inputs to LOG_ZERO exactly (x + finite == x at 2e20; LOG_ADD returns the other operand
+    // when one is LOG_ZERO), so rows a lane has not reached yet and columns beyond L2 stay LOG_ZERO.
     // ------------------------------------------------------------------ sweep 1: forward
-    float totF = LZ;
+    float endM = LZ, endX = LZ, endY = LZ;  // F_k(L1, L2)
     {
       float pM[W], pX[W], pY[W];
 #pragma unroll
@@ -106,48 +111,44 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
         const int i = s - t;
         const bool rowv = (i >= 0) && (i <= L1);
         const int c1 = (rowv && i >= 1) ? (int)s1[i - 1] : 6;
-        float rM = shfl_up1<G>(lastM), rX = shfl_up1<G>(lastX), rY = shfl_up1<G>(lastY);
-        if (t == 0) { rM = LZ; rX = LZ; rY = LZ; }
+        const float rM = shift_up1<G>(lastM, LZ, t), rX = shift_up1<G>(lastX, LZ, t), rY = shift_up1<G>(lastY, LZ, t);
         float dM = dgM, dX = dgX, dY = dgY;  // (i-1, j-1)
         float lM = rM, lY = rY;              // (i, j-1)
         const float insc1 = s_ins[c1];
 #pragma unroll
         for (int c = 0; c < W; ++c) {
           const int j = t * W + c;
-          const bool v = rowv && (j <= L2);
           const float mt = s_match[c1 * 8 + cc[c]];
           // ProbabilisticModel.h:152-155
           float m = dM + tMM;
-          m = pc_log_add(m, dX + tXM);
-          m = pc_log_add(m, dY + tYM);
+          m = pc_log_add_t<LUT>(&s_tab, m, dX + tXM);
+          m = pc_log_add_t<LUT>(&s_tab, m, dY + tYM);
           m += mt;
           // :159-161 and :165-167
-          float x = insc1 + pc_log_add(pM[c] + tMX, pX[c] + tXX);
-          float y = s_ins[cc[c]] + pc_log_add(lM + tMY, lY + tYY);
-          // initial cells, :123-131 (cells with i<=1 && j<=1 are not touched by the recursion, :150)
-          if (i <= 1 && j <= 1) {
-            m = (i == 1 && j == 1) ? fM11 : LZ;
-            x = (i == 1 && j == 0) ? fX10 : LZ;
-            y = (i == 0 && j == 1) ? fY01 : LZ;
+          float x = insc1 + pc_log_add_t<LUT>(&s_tab, pM[c] + tMX, pX[c] + tXX);
+          float y = s_ins[cc[c]] + pc_log_add_t<LUT>(&s_tab, lM + tMY, lY + tYY);
+          if (c <= 1) {  // j <= 1 needs c <= 1: initial cells, :123-131 (cells with i<=1 && j<=1 are skipped by :150)
+            if (i <= 1 && j <= 1) {
+              m = (i == 1 && j == 1) ? fM11 : LZ;
+              x = (i == 1 && j == 0) ? fX10 : LZ;
+              y = (i == 0 && j == 1) ? fY01 : LZ;
+            }
           }
-          if (!v) { m = LZ; x = LZ; y = LZ; }
           dM = pM[c]; dX = pX[c]; dY = pY[c];
           pM[c] = m; pX[c] = x; pY[c] = y;
           lM = m; lY = y;
-          if (v) slab[(size_t)(s * W + c) * 64 + lane] = m;
-          if (v && i == L1 && j == L2) {  // ComputeTotalProbability, :341-347 (B_k(L1,L2) = init_k)
-            float tf = LZ;
-            tf = pc_log_add(tf, m + i0);
-            tf = pc_log_add(tf, x + i1);
-            tf = pc_log_add(tf, y + i2);
-            totF = tf;
-          }
+          slab[(size_t)(s * W + c) * 64 + lane] = m;  // slot (s,c,lane) is private to this lane: no guard needed
+          if (i == L1 && j == L2) { endM = m; endX = x; endY = y; }
         }
         dgM = rM; dgX = rX; dgY = rY;
         lastM = pM[W - 1]; lastX = pX[W - 1]; lastY = pY[W - 1];
       }
     }
     const int tlast = (L2 >= 0 ? L2 : 0) / W;  // lane (within group) that owns column L2
+    float totF = LZ;  // ComputeTotalProbability, :341-347 (B_k(L1,L2) = init_k)
+    totF = pc_log_add_t<LUT>(&s_tab, totF, endM + i0);
+    totF = pc_log_add_t<LUT>(&s_tab, totF, endX + i1);
+    totF = pc_log_add_t<LUT>(&s_tab, totF, endY + i2);
     totF = __shfl(totF, g * G + tlast);
 
     // ------------------------------------------------------------------ sweep 2: backward
@@ -164,8 +165,7 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
         const bool rowv = (i >= 0) && (i <= L1);
         const int sf = i + t;  // forward step that stored row i for this lane (wave-uniform per group)
         const int c1 = (rowv && i < L1) ? (int)s1[i] : 6;
-        float rM = shfl_down1<G>(firstM), rY = shfl_down1<G>(firstY);
-        if (t == G - 1) { rM = LZ; rY = LZ; }
+        const float rM = shift_down1<G>(firstM, LZ, t), rY = shift_down1<G>(firstY, LZ, t);
         float dM = dgM;  // B_M(i+1, j+1)
         float rgY = rY;  // B_Y(i, j+1)
         const float insc1 = s_ins[c1];
@@ -178,31 +178,31 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
 #pragma unroll
         for (int c = W - 1; c >= 0; --c) {
           const int j = t * W + c;
-          const bool v = rowv && (j <= L2);
           const int c2 = cc[c + 1];  // class of s2[j] (iter2[j+1]); 'other' beyond the end
           float bm = LZ, bx = LZ, by = LZ;
           if (i == L1 && j == L2) { bm = i0; bx = i1; by = i2; }  // :213-214
           // :233-237
           const float pxy = dM + s_match[c1 * 8 + c2];
-          bm = pc_log_add(bm, pxy + tMM);
-          bx = pc_log_add(bx, pxy + tXM);
-          by = pc_log_add(by, pxy + tYM);
+          bm = pc_log_add_t<LUT>(&s_tab, bm, pxy + tMM);
+          bx = pc_log_add_t<LUT>(&s_tab, bx, pxy + tXM);
+          by = pc_log_add_t<LUT>(&s_tab, by, pxy + tYM);
           // :238-243
           const float tx = pX[c] + insc1;
-          bm = pc_log_add(bm, tx + tMX);
-          bx = pc_log_add(bx, tx + tXX);
+          bm = pc_log_add_t<LUT>(&s_tab, bm, tx + tMX);
+          bx = pc_log_add_t<LUT>(&s_tab, bx, tx + tXX);
           // :244-249
           const float ty = rgY + s_ins[c2];
-          bm = pc_log_add(bm, ty + tMY);
-          by = pc_log_add(by, ty + tYY);
-          if (!v) { bm = LZ; bx = LZ; by = LZ; }
+          bm = pc_log_add_t<LUT>(&s_tab, bm, ty + tMY);
+          by = pc_log_add_t<LUT>(&s_tab, by, ty + tYY);
           dM = pM[c];
           pM[c] = bm; pX[c] = bx;
           rgY = by;
-          if (v) slab[(size_t)(sf * W + c) * 64 + lane] = fwd[c] + bm;  // forward[ij] + backward[ij], :395
-          if (v && i == 1 && j == 1) capM = bm;
-          if (v && i == 1 && j == 0) capX = bx;
-          if (v && i == 0 && j == 1) capY = by;
+          if (rowv && j <= L2) slab[(size_t)(sf * W + c) * 64 + lane] = fwd[c] + bm;  // forward[ij] + backward[ij], :395
+          if (c <= 1) {  // columns 0 and 1 only exist for c <= 1
+            if (i == 1 && j == 1) capM = bm;
+            if (i == 1 && j == 0) capX = bx;
+            if (i == 0 && j == 1) capY = by;
+          }
           if (c == 0) firstY = by;
         }
         dgM = rM;
@@ -214,14 +214,15 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
     capX = __shfl(capX, g * G);
     capY = __shfl(capY, g * G + (1 / W));
     float totB = fM11 + capM;
-    totB = pc_log_add(totB, fX10 + capX);
-    totB = pc_log_add(totB, fY01 + capY);
+    totB = pc_log_add_t<LUT>(&s_tab, totB, fX10 + capX);
+    totB = pc_log_add_t<LUT>(&s_tab, totB, fY01 + capY);
     const float total = (totF + totB) / 2;
 
     // sweeps 3 + 4 (pair_sweeps.h): ComputePosteriorMatrix :395 = EXP(min(LOG_ONE, F+B-total)), then sparse outputs
-    pair_finish<G, W>(a, slab, s_rowptr, lane, t, g, L1, L2, nsteps, tlast, act, task, th, [total](float sv) {
+    const pc_tables* tab = &s_tab;
+    pair_finish<G, W>(a, slab, s_rowptr, lane, t, g, L1, L2, nsteps, tlast, act, task, th, [total, tab](float sv) {
       const float e = sv - total;
-      return pc_exp(e < 0.0f ? e : 0.0f);
+      return pc_exp_t(tab, e < 0.0f ? e : 0.0f);
     });
   }
 }
@@ -230,16 +231,22 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
 // host side
 // ---------------------------------------------------------------------------------------------
 typedef void (*pairhmm3_fn)(dafs_pairhmm3_args, uint32_t, uint32_t);
-struct variant { int G, W; pairhmm3_fn fn; };
-#define V(G, W) {G, W, k_pairhmm3<G, W>}
+struct variant { int G, W; pairhmm3_fn fn; pairhmm3_fn fn_alt; };
+#define V(G, W) {G, W, k_pairhmm3<G, W, true>, nullptr}
+#define V2(G, W) {G, W, k_pairhmm3<G, W, true>, k_pairhmm3<G, W, false>}
 static const variant k_variants[] = {
-    V(16, 2), V(16, 3), V(16, 4), V(16, 5), V(16, 6), V(16, 8), V(16, 10), V(16, 11), V(16, 12), V(16, 14), V(16, 16),
-    V(32, 2), V(32, 3), V(32, 4), V(32, 5), V(32, 6), V(32, 8), V(32, 10), V(32, 12), V(32, 14), V(32, 16),
-    V(64, 1), V(64, 2), V(64, 3), V(64, 4), V(64, 5), V(64, 6), V(64, 8), V(64, 10), V(64, 12), V(64, 14), V(64, 16), V(64, 24), V(64, 32),
+    V(16, 2), V(16, 3), V(16, 4), V(16, 5), V(16, 6), V(16, 8), V(16, 10), V2(16, 11), V(16, 12), V(16, 14), V(16, 16),
+    V(32, 2), V(32, 3), V(32, 4), V(32, 5), V2(32, 6), V(32, 8), V(32, 10), V(32, 12), V(32, 14), V(32, 16),
+    V(64, 1), V(64, 2), V2(64, 3), V(64, 4), V(64, 5), V(64, 6), V(64, 8), V(64, 10), V(64, 12), V(64, 14), V(64, 16), V(64, 24), V(64, 32),
 };
 #undef V
+#undef V2
 
-static const uint32_t kMaxWaves = 256 * 8;  // 256 CUs x 2 waves per SIMD
+static uint32_t max_waves() {  // persistent wavefronts: 256 CUs x 4 SIMDs x waves per SIMD (DAFS_HIP_WAVES_PER_SIMD, default 2)
+  const char* e = getenv("DAFS_HIP_WAVES_PER_SIMD");
+  const int w = e ? atoi(e) : 2;
+  return 1024u * (uint32_t)(w < 1 ? 1 : (w > 8 ? 8 : w));
+}
 
 }  // namespace dafs
 
@@ -256,7 +263,7 @@ extern "C" int dafs_hipk_pairhmm_plan(uint32_t ntasks, uint32_t max_len1, uint32
     if ((uint64_t)v.G * v.W < (uint64_t)max_len2 + 1) continue;
     if (force_g && v.G != force_g) continue;
     const uint64_t waves = ((uint64_t)ntasks + (64 / v.G) - 1) / (64 / v.G);
-    const uint64_t rounds = (waves + kMaxWaves - 1) / kMaxWaves;
+    const uint64_t rounds = (waves + max_waves() - 1) / max_waves();
     const double cost = (double)(max_len1 + v.G) * v.W * (double)rounds;
     if (!best || cost < best_cost) { best = &v; best_cost = cost; }
   }
@@ -264,7 +271,7 @@ extern "C" int dafs_hipk_pairhmm_plan(uint32_t ntasks, uint32_t max_len1, uint32
   const uint64_t waves = ((uint64_t)ntasks + (64 / best->G) - 1) / (64 / best->G);
   plan->group = best->G;
   plan->width = best->W;
-  uint32_t nw = (uint32_t)(waves < kMaxWaves ? waves : kMaxWaves);
+  uint32_t nw = (uint32_t)(waves < max_waves() ? waves : max_waves());
   nw = (nw + 3) & ~3u;  // whole workgroups of 4 waves
   plan->nwaves = nw;
   plan->slab_steps = max_len1 + best->G;
@@ -282,6 +289,7 @@ extern "C" int dafs_hipk_pairhmm3_launch(const dafs_pairhmm3_args* args, const d
   const uint32_t rp_cap = plan->slab_steps - plan->group + 1;  // max_len1 + 1 row pointers
   const size_t lds = (size_t)4 * (64 / v->G) * rp_cap * sizeof(uint32_t);
   if (lds > 60 * 1024) return DAFS_HIP_ETOOLONG;
-  hipLaunchKernelGGL(v->fn, dim3(plan->nwaves / 4), dim3(256), lds, (hipStream_t)hip_stream, *args, plan->slab_steps, rp_cap);
+  const char* alt = getenv("DAFS_HIP_PC_SELECT");  // tuning switch: coefficient selects instead of the LDS table
+  hipLaunchKernelGGL((alt && atoi(alt) && v->fn_alt) ? v->fn_alt : v->fn, dim3(plan->nwaves / 4), dim3(256), lds, (hipStream_t)hip_stream, *args, plan->slab_steps, rp_cap);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }

@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void k_pairhmm5(dafs_pairhmm5_args a, uint32_t
         const bool rowv = (i >= 0) && (i <= L1);
         int xi = (rowv && i >= 1) ? (int)s1[i - 1] : 4;
         xi = xi < 4 ? xi : 4;
-        float rM = shfl_up1<G>(lsM), rX = shfl_up1<G>(lsX), rY = shfl_up1<G>(lsY), r2X = shfl_up1<G>(ls2X), r2Y = shfl_up1<G>(ls2Y);
-        if (t == 0) { rM = NI; rX = NI; rY = NI; r2X = NI; r2Y = NI; }
+        const float rM = shift_up1<G>(lsM, NI, t), rX = shift_up1<G>(lsX, NI, t), rY = shift_up1<G>(lsY, NI, t);
+        const float r2X = shift_up1<G>(ls2X, NI, t), r2Y = shift_up1<G>(ls2Y, NI, t);
         float dM = dgM, dX = dgX, dY = dgY, d2X = dg2X, d2Y = dg2Y;  // (i-1, j-1)
         float lM = rM, lX = rX, lY = rY, l2X = r2X, l2Y = r2Y;       // (i, j-1)
         const float insx = 0.0f + s_insert[xi];
@@ -167,8 +167,7 @@ __global__ __launch_bounds__(256) void k_pairhmm5(dafs_pairhmm5_args a, uint32_t
         const int sf = i + t;
         int xn = (rowv && i < L1) ? (int)s1[i] : 4;  // x[i+1]
         xn = xn < 4 ? xn : 4;
-        float rM = shfl_down1<G>(fsM), rY = shfl_down1<G>(fsY), r2Y = shfl_down1<G>(fs2Y);
-        if (t == G - 1) { rM = NI; rY = NI; r2Y = NI; }
+        const float rM = shift_down1<G>(fsM, NI, t), rY = shift_down1<G>(fsY, NI, t), r2Y = shift_down1<G>(fs2Y, NI, t);
         float dM = dgM;              // Fb[M](i+1, j+1)
         float gY = rY, g2Y = r2Y;    // Fb[IY](i, j+1), Fb[I2Y](i, j+1)
         const float insx = 0.0f + s_insert[xn];

@@ -58,4 +58,75 @@ __device__ __forceinline__ float pc_exp(float xf) {
   return (float)((((k4 * x + k3) * x + k2) * x + k1) * x + k0);
 }
 
+// ---- table-driven forms: same polynomials, coefficients fetched from LDS by one ds_read_b128
+// instead of a dozen selects.  pc_tables lives in LDS, filled by pc_tables_init.
+struct pc_tables {
+  float4 lookup[12];   // LOOKUP cubic (k3,k2,k1,k0) valid on ((k-1)/2, k/2], k = min(ceil(2x), 10)
+  double2 exp_hi[8];   // k4,k3 of the EXP quartics, index = clamp(exponent(|x|) + 2, 0, 6); [6] = zero
+  double2 exp_mid[8];  // k2,k1
+  double exp_lo[8];    // k0
+};
+
+__device__ __forceinline__ void pc_tables_init(pc_tables* t, int tid) {
+  if (tid == 0) {
+    const float4 c0 = make_float4(-0.009350833524763f, 0.130659527668286f, 0.498799810682272f, 0.693203116424741f);  // x <= 1
+    const float4 c1 = make_float4(-0.014532321752540f, 0.139942324101744f, 0.495635523139337f, 0.692140569840976f);  // x <= 2.5
+    const float4 c2 = make_float4(-0.004605031767994f, 0.063427417320019f, 0.695956496475118f, 0.514272634594009f);  // x <= 4.5
+    const float4 c3 = make_float4(-0.000458661602210f, 0.009695946122598f, 0.930734667215156f, 0.168037164329057f);  // else
+    for (int k = 0; k <= 10; ++k) t->lookup[k] = k <= 2 ? c0 : (k <= 5 ? c1 : (k <= 9 ? c2 : c3));
+    t->lookup[11] = c3;
+    const double e[6][5] = {
+        {0.03254409303190190000, 0.16280432765779600000, 0.49929760485974900000, 0.99995149601363700000, 0.99999925508501600000},
+        {0.01973899026052090000, 0.13822379685007000000, 0.48056651562365000000, 0.99326940370383500000, 0.99906756856399500000},
+        {0.00940528203591384000, 0.09414963667859410000, 0.40825793595877300000, 0.93933625499130400000, 0.98369508190545300000},
+        {0.00217245711583303000, 0.03484829428350620000, 0.22118199801337800000, 0.67049462206469500000, 0.83556950223398500000},
+        {0.00012398771025456900, 0.00349155785951272000, 0.03727721426017900000, 0.17974997741536900000, 0.33249299994217400000},
+        {0.00000051741713416603, 0.00002721456879608080, 0.00053418601865636800, 0.00464101989351936000, 0.01507447981459420000}};
+    for (int k = 0; k < 8; ++k) {
+      const bool z = k >= 6;
+      t->exp_hi[k] = z ? make_double2(0.0, 0.0) : make_double2(e[k][0], e[k][1]);
+      t->exp_mid[k] = z ? make_double2(0.0, 0.0) : make_double2(e[k][2], e[k][3]);
+      t->exp_lo[k] = z ? 0.0 : e[k][4];
+    }
+  }
+}
+
+// LOOKUP (ScoreType.h:187-198).  The breakpoints 1.0, 2.5, 4.5 are multiples of 1/2 and every piece
+// is closed on the right, so the piece is a function of ceil(2x): no compare chain.
+__device__ __forceinline__ float pc_lookup_t(const pc_tables* t, float x) {
+  const unsigned k = (unsigned)fminf(ceilf(x * 2.0f), 10.0f);  // x >= 0 here
+  const float4 q = t->lookup[k];
+  return ((q.x * x + q.y) * x + q.z) * x + q.w;
+}
+
+// LOG_ADD / LOG_PLUS_EQUALS (ScoreType.h:233-262).  LUT = true fetches the cubic from LDS, LUT = false
+// selects it (pc_lookup).  Two identities keep the instruction count down without changing a bit:
+//  * min/max instead of compare+selects (no NaN reaches a DP cell);
+//  * the reference's `lo == LOG_ZERO` exit is implied by its `hi - lo >= 7.5` exit: LOG_ZERO is
+//    -2e20, whose ulp is 1.8e13, so hi - LOG_ZERO >= 7.5 unless hi == LOG_ZERO too, and then both
+//    exits give LOG_ZERO (LOOKUP(0) + LOG_ZERO rounds to LOG_ZERO).
+template <bool LUT>
+__device__ __forceinline__ float pc_log_add_t(const pc_tables* t, float x, float y) {
+  const float lo = fminf(x, y);
+  const float hi = fmaxf(x, y);
+  const float d = hi - lo;
+  const float r = (LUT ? pc_lookup_t(t, d) : pc_lookup(d)) + lo;
+  return d >= 7.5f ? hi : r;
+}
+
+// EXP (ScoreType.h:37-57) for x <= 0.  Piece boundaries are -1/2, -1, -2, -4, -8, -16, i.e. the
+// binary exponent of |x| selects the piece; index 6 holds zeros (x <= -16 returns 0).
+__device__ __forceinline__ float pc_exp_t(const pc_tables* t, float xf) {
+  const float a = fmaxf(-xf, 1.0e-30f);                   // |x|, away from 0 so that the exponent is defined
+  int e;
+  (void)frexpf(a, &e);                                     // a = m * 2^e, m in [0.5, 1)
+  // x > -0.5 <=> a < 0.5 <=> e <= -1 ; -1 < x <= -0.5 <=> e == 0 ; ... ; -16 < x <= -8 <=> e == 4
+  // (piece boundaries are closed on the lower side: x <= -0.5 leaves piece 0, matching a >= 0.5 <=> e >= 0)
+  const int piece = min(max(e + 1, 0), 6);
+  const double2 h = t->exp_hi[piece], m = t->exp_mid[piece];
+  const double c = t->exp_lo[piece];
+  const double x = (double)xf;
+  return (float)((((h.x * x + h.y) * x + m.x) * x + m.y) * x + c);
+}
+
 }  // namespace dafs
