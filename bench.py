@@ -191,6 +191,19 @@ def main():
     alg_bytes = float((28 * (lens[px] + 1) * (lens[py] + 1)).sum())
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
+    # HBM traffic of the dominant kernel: from the committed rocprofv3 PMC passes (profiles/*_pmc.json,
+    # collected and corrected as MI355X_MICROARCH.md prescribes); only quoted when it is the same kernel.
+    traffic = None
+    kernel_name = "k_pairhmm3<G=%d,W=%d" % (plan.group, plan.width)
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+            pm = json.load(open(f))
+            if pm.get("kernel", "").startswith(kernel_name) and world == 1 and n_seq == BASE_N and args.length == BASE_L:
+                traffic = pm["hbm_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        traffic = None
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(seqs, px, py, args.th)
@@ -227,7 +240,7 @@ def main():
                        "align_model": "ProbCons", "th": args.th,
                        "kernel": "k_pairhmm3<G=%d,W=%d> x %d waves" % (plan.group, plan.width, plan.nwaves)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
         }
