@@ -1,6 +1,8 @@
 // dafs_amd/csrc/capi_fold.cpp -- L1: base-pairing posteriors with the CONTRAfold model
 // (Fold::Model::calculate, reference src/fold.cpp:60-68, 174-207).
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -88,7 +90,7 @@ struct fold_job {
     memset(&s, 0, sizeof s);
     s.len = len; s.code_off = code_off; s.has_constraint = has_cons ? 1u : 0u; s.cons_off = cons_off;
     const uint64_t S = (uint64_t)(len + 1) * (len + 2) / 2;
-    s.iws_off = iws; iws += 4ull * (len + 2);
+    s.iws_off = iws; iws += 12ull * (len + 2);
     s.fws_off = fws; fws += 7 * S + 2ull * (len + 1);
     s.post_off = post; post += S;
     seqs.push_back(s);
@@ -122,10 +124,22 @@ int run_job(dafs_hip_ctx* c, const fold_job& job, const uint8_t* d_codes, const 
   B.fws = c->cf_fws.ptr;
   B.post = c->cf_post.ptr;
   B.logz = c->cf_logz.ptr;
+  B.stamps = nullptr;
+  if (getenv("DAFS_HIP_CF_STAMPS")) {
+    if ((rc = c->cf_stamps.reserve(8))) return rc;
+    B.stamps = c->cf_stamps.ptr;
+  }
   *out = B;
   uint32_t max_len = 0;
   for (const cf_seq& q : job.seqs) max_len = std::max(max_len, q.len);
-  return contrafold_launch(B, (uint32_t)job.seqs.size(), max_len, c->stream);
+  rc = contrafold_launch(B, (uint32_t)job.seqs.size(), max_len, c->stream);
+  if (!rc && B.stamps) {
+    unsigned long long h[8] = {0};
+    if (!hip_check(hipMemcpy(h, B.stamps, sizeof h, hipMemcpyDeviceToHost)))
+      fprintf(stderr, "k_contrafold block 0 (us): inside %.0f | F5i %.0f | F5o %.0f | outside %.0f\n", (h[1] - h[0]) / 100.0, (h[2] - h[1]) / 100.0,
+              (h[3] - h[2]) / 100.0, (h[4] - h[3]) / 100.0);
+  }
+  return rc;
 }
 
 }  // namespace

@@ -27,7 +27,7 @@ struct cf_seq {
   uint32_t code_off;       // into cf_batch.codes
   uint32_t has_constraint;
   uint32_t cons_off;       // into cf_batch.cons (len+1 ints, index = position)
-  uint64_t iws_off;        // unused (integer tables live in LDS)
+  uint64_t iws_off;        // into cf_batch.iws: 12*(len+2) ints (integer side tables, written by k_contrafold)
   uint64_t fws_off;        // into cf_batch.fws: 7*S + 2*(len+1) floats, S = (len+1)(len+2)/2
   uint64_t post_off;       // into cf_batch.post: S floats
 };
@@ -41,6 +41,7 @@ struct cf_batch {
   float* fws;
   float* post;              // triangular posteriors, reference layout
   float* logz;              // optional [nseq]
+  unsigned long long* stamps;  // optional [8]: 100 MHz timestamps of block 0 at phase boundaries (tuning aid)
 };
 
 void contrafold_default_params(cf_params* p);  // host: tables + caches

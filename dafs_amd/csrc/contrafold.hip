@@ -33,8 +33,15 @@ struct cf_ctx {  // per-workgroup view
   const int* map;        // constraint mapping per position (-1 unknown, 0 unpaired, else partner)
   const int* cum;        // cum[t] = number of positions 1..t that may NOT be unpaired
   const int* off;        // row offsets of the triangular tables
+  // Pairing partners by symbol: plist[y*L ..] = ascending positions whose symbol pairs with symbol y
+  // (AU, GU, CG), pcnt[y*(L+2) + j] = how many of them are <= j.  Lets the single-branch loops
+  // visit only pairable (p+1, q) instead of testing every q.
+  const int* plist;
+  const int* pcnt;
+  float* ring;           // LDS ring of the last 33 spans of FC (inside) / FCo (outside): ring[(span % 33)*(L+1) + row]; null = none
   const cf_params* P;    // score tables (LDS copy)
 };
+#define CF_RING 33
 
 __device__ __forceinline__ bool cf_comp(int a, int b) {  // AU, GU, CG (InferenceEngine ctor)
   return (a == 0 && b == 3) || (a == 3 && b == 0) || (a == 2 && b == 3) || (a == 3 && b == 2) || (a == 1 && b == 2) || (a == 2 && b == 1);
@@ -76,13 +83,35 @@ __device__ __forceinline__ float cf_single_nuc(const cf_ctx& c, int i, int j, in
 // ---------------------------------------------------------------------------------------------
 // inside cell (i,j), InferenceEngine.ipp:3392-3688
 // ---------------------------------------------------------------------------------------------
+// constraint part of allow_paired for a symbol-compatible pair (a < q)
+__device__ __forceinline__ bool cf_map_ok(const cf_ctx& c, int a, int q) {
+  const int ma = c.map[a], mq = c.map[q];
+  return (ma == -1 || ma == q) && (mq == -1 || mq == a);
+}
+__device__ __forceinline__ float cf_fc_load(const cf_ctx& c, const float* FC, int row, int col) {  // FC[row][col], recent spans from LDS
+  return c.ring ? c.ring[((col - row) % CF_RING) * (c.L + 1) + row] : FC[c.off[row] + col];
+}
+
 __device__ void cf_inside_cell(const cf_ctx& c, int i, int j, float* FCi, float* FMi, float* FM1i) {
   const int L = c.L;
   const int* off = c.off;
   float FM2i = CONTRA_NEG_INF;
-  if (i + 2 <= j)
-    for (int k = i + 1; k < j; k++) FM2i = contra_lpe(FM2i, FM1i[off[i] + k] + FMi[off[k] + j]);
-  if (0 < i && j < L && cf_allow_paired(c, i, j + 1)) {
+  if (i + 2 <= j) {
+    // sequential fold over k (:3392-3405); loads of the next four addends are issued before the
+    // dependent log-sum-exp chain consumes the current four
+    int k = i + 1;
+    for (; k + 4 <= j; k += 4) {
+      const float a0 = FM1i[off[i] + k] + FMi[off[k] + j];
+      const float a1 = FM1i[off[i] + k + 1] + FMi[off[k + 1] + j];
+      const float a2 = FM1i[off[i] + k + 2] + FMi[off[k + 2] + j];
+      const float a3 = FM1i[off[i] + k + 3] + FMi[off[k + 3] + j];
+      FM2i = contra_lpe(contra_lpe(contra_lpe(contra_lpe(FM2i, a0), a1), a2), a3);
+    }
+    for (; k < j; k++) FM2i = contra_lpe(FM2i, FM1i[off[i] + k] + FMi[off[k] + j]);
+  }
+  float fc = CONTRA_NEG_INF;
+  const bool closing = (0 < i && j < L && cf_allow_paired(c, i, j + 1));
+  if (closing) {
     float sum = CONTRA_NEG_INF;
     if (cf_all_unpaired(c, i, j)) sum = contra_lpe(sum, cf_hairpin(c, i, j));
     const float score_helix = (i + 2 <= j ? cf_base_pair(c, i + 1, j) + cf_helix_stacking(c, i, j + 1) : 0.0f);
@@ -91,24 +120,31 @@ __device__ void cf_inside_cell(const cf_ctx& c, int i, int j, float* FCi, float*
     for (int p = i; p <= pmax; p++) {
       if (p > i && !cf_unpaired_pos(c, p)) break;
       const int q_min = max(p + 2, p - i + j - CF_MAX_SINGLE);
-      const float* FCptr = FCi + off[p + 1] - 1;
-      for (int q = j; q >= q_min; q--) {
-        if (q < j && !cf_unpaired_pos(c, q + 1)) break;
-        if (!cf_allow_paired(c, p + 1, q)) continue;
+      const int sy = c.s[p + 1];
+      if (sy == 4) continue;  // a non-ACGU symbol pairs with nothing
+      const int* pl = c.plist + sy * L;
+      for (int e = c.pcnt[sy * (L + 2) + j] - 1; e >= 0; --e) {  // partners q of p+1, q = j downwards
+        const int q = pl[e];
+        if (q < q_min) break;
+        if (q < j && !cf_all_unpaired(c, q, j)) break;
+        if (!cf_map_ok(c, p + 1, q)) continue;
+        const float inner = cf_fc_load(c, FCi, p + 1, q - 1);
         const float score = (p == i && q == j)
-                                ? (score_helix + FCptr[q])
-                                : (score_other + c.P->cache_single[(p - i) * 31 + (j - q)] + FCptr[q] + cf_base_pair(c, p + 1, q) +
+                                ? (score_helix + inner)
+                                : (score_other + c.P->cache_single[(p - i) * 31 + (j - q)] + inner + cf_base_pair(c, p + 1, q) +
                                    cf_junction_b(c, q, p) + cf_single_nuc(c, i, j, p, q));
         sum = contra_lpe(sum, score);
       }
     }
     sum = contra_lpe(sum, FM2i + cf_junction_a(c, i, j) + c.P->multi_paired + c.P->multi_base);
     FCi[off[i] + j] = sum;
+    fc = sum;
   }
+  if (c.ring) c.ring[((j - i) % CF_RING) * (L + 1) + i] = fc;
   if (0 < i && i + 2 <= j && j < L) {
     float sum = CONTRA_NEG_INF;
     if (cf_allow_paired(c, i + 1, j))
-      sum = contra_lpe(sum, FCi[off[i + 1] + j - 1] + cf_junction_a(c, j, i) + c.P->multi_paired + cf_base_pair(c, i + 1, j));
+      sum = contra_lpe(sum, cf_fc_load(c, FCi, i + 1, j - 1) + cf_junction_a(c, j, i) + c.P->multi_paired + cf_base_pair(c, i + 1, j));
     if (cf_unpaired_pos(c, i + 1)) sum = contra_lpe(sum, FM1i[off[i + 1] + j] + MULTI_UNPAIRED);
     FM1i[off[i] + j] = sum;
     float sm = CONTRA_NEG_INF;
@@ -129,8 +165,17 @@ __device__ void cf_outside_cell(const cf_ctx& c, int a, int b, const float* FCi,
   const int* off = c.off;
   // ---- FMo[a][b]: block 4 of sources (i,b), i = 0..a-1 (:4040-4068), then block 1 of source (a,b+1) (:3770-3777)
   float fmo = CONTRA_NEG_INF;
-  if (a < b)
-    for (int i = 0; i < a; i++) fmo = contra_lpe(fmo, FM2o[off[i] + b] + FM1i[off[i] + a]);
+  if (a < b) {
+    int i = 0;
+    for (; i + 4 <= a; i += 4) {
+      const float t0 = FM2o[off[i] + b] + FM1i[off[i] + a];
+      const float t1 = FM2o[off[i + 1] + b] + FM1i[off[i + 1] + a];
+      const float t2 = FM2o[off[i + 2] + b] + FM1i[off[i + 2] + a];
+      const float t3 = FM2o[off[i + 3] + b] + FM1i[off[i + 3] + a];
+      fmo = contra_lpe(contra_lpe(contra_lpe(contra_lpe(fmo, t0), t1), t2), t3);
+    }
+    for (; i < a; i++) fmo = contra_lpe(fmo, FM2o[off[i] + b] + FM1i[off[i] + a]);
+  }
   if (0 < a && a + 2 <= b + 1 && b + 1 < L && cf_unpaired_pos(c, b + 1)) fmo = contra_lpe(fmo, FMo[off[a] + b + 1] + MULTI_UNPAIRED);
   FMo[off[a] + b] = fmo;
 
@@ -147,33 +192,52 @@ __device__ void cf_outside_cell(const cf_ctx& c, int a, int b, const float* FCi,
       const int l1 = p - i;
       if (l1 > 0 && !cf_all_unpaired(c, i, p)) continue;
       const int jmax = min(L - 1, q + CF_MAX_SINGLE - l1);
-      for (int j = jmax; j >= q; j--) {
-        const int l2 = j - q;
-        if (i == p && j == q) {
-          // source (p,q): block 2 (:3787-3789) comes before its own single-branch scatter
-          if (0 < p && p + 2 <= q && q < L)
-            fco = contra_lpe(fco, FM1o[off[p] + q] + cf_junction_a(c, q, p) + c.P->multi_paired + cf_base_pair(c, p + 1, q));
-          if (cf_allow_paired(c, i, j + 1)) {
-            const float score_helix = FCo[off[i] + j] + cf_base_pair(c, i + 1, j) + cf_helix_stacking(c, i, j + 1);
-            fco = contra_lpe(fco, score_helix);
-          }
-          continue;
+      const int sy = c.s[i];
+      if (sy != 4) {
+        // sources (i,j) close the pair (i, j+1): walk the partners of i from jmax+1 down to q+2 (q+1 is the
+        // (p,q) / bulge-free slot handled below for i == p, and a normal source for i < p)
+        const int* pl = c.plist + sy * L;
+        const int lowest = (i == p) ? q + 2 : q + 1;
+        for (int e = c.pcnt[sy * (L + 2) + jmax + 1] - 1; e >= 0; --e) {
+          const int j = pl[e] - 1;
+          if (j + 1 < lowest) break;
+          if (!cf_map_ok(c, i, j + 1)) continue;
+          const int l2 = j - q;
+          if (l2 > 0 && !cf_all_unpaired(c, q, j)) continue;
+          const float src = cf_fc_load(c, FCo, i, j);
+          const float score_other = src + cf_junction_b(c, i, j);
+          fco = contra_lpe(fco, score_other + c.P->cache_single[l1 * 31 + l2] + cf_base_pair(c, p + 1, q) + cf_junction_b(c, q, p) +
+                                    cf_single_nuc(c, i, j, p, q));
         }
-        if (!cf_allow_paired(c, i, j + 1)) continue;
-        if (l2 > 0 && !cf_all_unpaired(c, q, j)) continue;
-        const float score_other = FCo[off[i] + j] + cf_junction_b(c, i, j);
-        fco = contra_lpe(fco, score_other + c.P->cache_single[l1 * 31 + l2] + cf_base_pair(c, p + 1, q) + cf_junction_b(c, q, p) +
-                                  cf_single_nuc(c, i, j, p, q));
+      }
+      if (i == p && q <= jmax) {
+        // source (p,q): block 2 (:3787-3789) comes before its own single-branch scatter (helix term)
+        if (0 < p && p + 2 <= q && q < L)
+          fco = contra_lpe(fco, FM1o[off[p] + q] + cf_junction_a(c, q, p) + c.P->multi_paired + cf_base_pair(c, p + 1, q));
+        if (cf_allow_paired(c, p, q + 1)) {
+          const float score_helix = cf_fc_load(c, FCo, p, q) + cf_base_pair(c, p + 1, q) + cf_helix_stacking(c, p, q + 1);
+          fco = contra_lpe(fco, score_helix);
+        }
       }
     }
     FCo[off[a] + b] = fco;
   }
+  if (c.ring) c.ring[((b - a) % CF_RING) * (L + 1) + a] = fco;
 
   // ---- FM1o[a][b]: block 2 of source (a-1,b), block 4 of sources (a,j) j = L..b+1, block 1 of source (a,b)
   float fm1o = CONTRA_NEG_INF;
   if (0 < a - 1 && a - 1 + 2 <= b && b < L && cf_unpaired_pos(c, a)) fm1o = contra_lpe(fm1o, FM1o[off[a - 1] + b] + MULTI_UNPAIRED);
-  if (a < b)
-    for (int j = L; j > b; j--) fm1o = contra_lpe(fm1o, FM2o[off[a] + j] + FMi[off[b] + j]);
+  if (a < b) {
+    int j = L;
+    for (; j - 4 >= b; j -= 4) {
+      const float t0 = FM2o[off[a] + j] + FMi[off[b] + j];
+      const float t1 = FM2o[off[a] + j - 1] + FMi[off[b] + j - 1];
+      const float t2 = FM2o[off[a] + j - 2] + FMi[off[b] + j - 2];
+      const float t3 = FM2o[off[a] + j - 3] + FMi[off[b] + j - 3];
+      fm1o = contra_lpe(contra_lpe(contra_lpe(contra_lpe(fm1o, t0), t1), t2), t3);
+    }
+    for (; j > b; j--) fm1o = contra_lpe(fm1o, FM2o[off[a] + j] + FMi[off[b] + j]);
+  }
   const bool live = (0 < a && a + 2 <= b && b < L);
   if (live) fm1o = contra_lpe(fm1o, fmo);
   FM1o[off[a] + b] = fm1o;
@@ -200,10 +264,20 @@ __device__ float cf_posterior_cell(const cf_ctx& c, int a, int q, const float* F
       const int l1 = p - i;
       if (l1 > 0 && !cf_all_unpaired(c, i, p)) break;  // larger l1 only adds more positions
       const int jmax = min(L - 1, q + CF_MAX_SINGLE - l1);
-      for (int j = q; j <= jmax; j++) {
-        const int l2 = j - q;
-        if (l2 > 0 && !cf_all_unpaired(c, q, j)) break;
-        if (cf_allow_paired(c, i, j + 1)) {
+      const int sy = c.s[i];
+      bool slot_done = (i != p);  // the (p,q) slot carries the multi-loop term even when (p,q+1) cannot pair
+      if (sy != 4) {
+        const int* pl = c.plist + sy * L;
+        const int e1 = c.pcnt[sy * (L + 2) + jmax + 1];
+        for (int e = c.pcnt[sy * (L + 2) + q]; e < e1; ++e) {  // partners j+1 of i, j = q upwards
+          const int j = pl[e] - 1;
+          const int l2 = j - q;
+          if (l2 > 0 && !cf_all_unpaired(c, q, j)) break;
+          if (!slot_done && j > q) {  // passed the (p,q) slot without a helix term
+            if (0 < p && p + 2 <= q) acc += contra_exp(FM1o[off[p] + q] + inner + cf_junction_a(c, q, p) + c.P->multi_paired + cf_base_pair(c, p + 1, q) - Z);
+            slot_done = true;
+          }
+          if (!cf_map_ok(c, i, j + 1)) continue;
           const float outside = FCo[off[i] + j] - Z;
           float term;
           if (i == p && j == q) term = contra_exp((outside + cf_base_pair(c, i + 1, j) + cf_helix_stacking(c, i, j + 1)) + inner);
@@ -211,9 +285,14 @@ __device__ float cf_posterior_cell(const cf_ctx& c, int a, int q, const float* F
             term = contra_exp((outside + cf_junction_b(c, i, j)) + c.P->cache_single[l1 * 31 + l2] + inner + cf_base_pair(c, p + 1, q) +
                               cf_junction_b(c, q, p) + cf_single_nuc(c, i, j, p, q));
           acc += term;
+          if (i == p && j == q) {  // multi-loop closing pair, :4741-4745 (source (p,q), right after its single-branch block)
+            if (0 < p && p + 2 <= q) acc += contra_exp(FM1o[off[p] + q] + inner + cf_junction_a(c, q, p) + c.P->multi_paired + cf_base_pair(c, p + 1, q) - Z);
+            slot_done = true;
+          }
         }
-        if (i == p && j == q && 0 < p && p + 2 <= q)  // multi-loop closing pair, :4741-4745 (source (p,q), after its single-branch block)
-          acc += contra_exp(FM1o[off[p] + q] + inner + cf_junction_a(c, q, p) + c.P->multi_paired + cf_base_pair(c, p + 1, q) - Z);
+      }
+      if (!slot_done) {
+        if (0 < p && p + 2 <= q) acc += contra_exp(FM1o[off[p] + q] + inner + cf_junction_a(c, q, p) + c.P->multi_paired + cf_base_pair(c, p + 1, q) - Z);
       }
     }
   }
@@ -224,7 +303,21 @@ __device__ float cf_posterior_cell(const cf_ctx& c, int a, int q, const float* F
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B) {
+// integer side tables of one sequence, in LDS: s, map, cum, off (L+2 each), plist (4*L), pcnt (4*(L+2))
+#define CF_INTS(L) (12 * ((L) + 2))
+
+__device__ void cf_bind(cf_ctx& c, int L, int* ints, float* ring, const cf_params* P) {
+  c.L = L;
+  int* s = ints;
+  int* map = s + (L + 2);
+  int* cum = map + (L + 2);
+  int* off = cum + (L + 2);
+  int* plist = off + (L + 2);
+  int* pcnt = plist + 4 * (L + 2);
+  c.s = s; c.map = map; c.cum = cum; c.off = off; c.plist = plist; c.pcnt = pcnt; c.ring = ring; c.P = P;
+}
+
+__global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B, int use_ring) {
   __shared__ cf_params sP;
   __shared__ float s_terms[CF_THREADS];
   {
@@ -236,18 +329,16 @@ __global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B) {
   const cf_seq sq = B.seqs[x];
   const int L = (int)sq.len;
   const int tid = threadIdx.x, nt = blockDim.x;
-  // symbols, constraint map, prefix counts and row offsets are read in every inner-loop test:
-  // keep them in LDS (4*(L+2) ints)
   extern __shared__ int s_ints[];
-  int* s = s_ints;               // L+2
-  int* map = s + (L + 2);        // L+2
-  int* cum = map + (L + 2);      // L+2
-  int* off = cum + (L + 2);      // L+2
+  float* ring = use_ring ? (float*)(s_ints + CF_INTS(L)) : nullptr;
+  cf_ctx c;
+  cf_bind(c, L, s_ints, ring, &sP);
+  int* s = (int*)c.s; int* map = (int*)c.map; int* cum = (int*)c.cum; int* off = (int*)c.off;
+  int* plist = (int*)c.plist; int* pcnt = (int*)c.pcnt;
   float* F = B.fws + sq.fws_off;
   const size_t SZ = (size_t)(L + 1) * (L + 2) / 2;
   float *FCi = F, *FMi = F + SZ, *FM1i = F + 2 * SZ, *FCo = F + 3 * SZ, *FMo = F + 4 * SZ, *FM1o = F + 5 * SZ, *FM2o = F + 6 * SZ;
   float *F5i = F + 7 * SZ, *F5o = F5i + (L + 1);
-  float* post = B.post + sq.post_off;
 
   // LoadSequence (:947-1097): symbols, row offsets, constraint bookkeeping
   for (int i = tid; i <= L + 1; i += nt) {
@@ -261,6 +352,8 @@ __global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B) {
     if (i <= L) off[i] = i * (2 * (L + 1) - i - 1) / 2;
   }
   for (size_t k = tid; k < 7 * SZ + 2 * (size_t)(L + 1); k += nt) F[k] = CONTRA_NEG_INF;
+  if (ring)
+    for (int k = tid; k < CF_RING * (L + 1); k += nt) ring[k] = CONTRA_NEG_INF;
   __syncthreads();
   if (tid == 0) {
     int run = 0;
@@ -268,15 +361,28 @@ __global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B) {
     for (int i = 1; i <= L; ++i) { run += (map[i] == -1 || map[i] == 0) ? 0 : 1; cum[i] = run; }
     cum[L + 1] = run;
   }
+  if (tid >= 64 && tid < 68) {  // partner list of symbol y: positions whose symbol pairs with y
+    const int y = tid - 64;
+    int n = 0;
+    pcnt[y * (L + 2)] = 0;
+    for (int q = 1; q <= L; ++q) {
+      if (cf_comp(y, s[q])) plist[y * L + n++] = q;
+      pcnt[y * (L + 2) + q] = n;
+    }
+    pcnt[y * (L + 2) + L + 1] = n;
+  }
   __syncthreads();
-  cf_ctx c;
-  c.L = L; c.s = s; c.map = map; c.cum = cum; c.off = off; c.P = &sP;
+  // keep the integer tables for the posterior kernel
+  for (int k = tid; k < CF_INTS(L); k += nt) B.iws[sq.iws_off + k] = s_ints[k];
 
+#define CF_STAMP(k) if (B.stamps && blockIdx.x == 0 && tid == 0) B.stamps[k] = wall_clock64()
+  CF_STAMP(0);
   // ---- inside: span ascending
   for (int d = 0; d <= L; ++d) {
     for (int i = tid; i + d <= L; i += nt) cf_inside_cell(c, i, i + d, FCi, FMi, FM1i);
     __syncthreads();
   }
+  CF_STAMP(1);
   // F5i (:3692-3717): a chain over j; the block prepares the addends, one lane folds them in order
   if (tid == 0) F5i[0] = 0.0f;
   __syncthreads();
@@ -305,10 +411,13 @@ __global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B) {
     }
   }
   const float Z = F5i[L];
+  CF_STAMP(2);
 
   // ---- outside.  F5o first (:3746-3767): lane k owns F5o[k]; at step tau all lanes take the
   // addend of j = L - tau + 1, whose F5o[j] was completed in the previous steps.
   if (tid == 0) F5o[L] = 0.0f;
+  if (ring)
+    for (int k = tid; k < CF_RING * (L + 1); k += nt) ring[k] = CONTRA_NEG_INF;
   __syncthreads();
   for (int j = L; j >= 1; --j) {
     const float f5oj = F5o[j];
@@ -323,17 +432,40 @@ __global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B) {
     }
     __syncthreads();
   }
+  CF_STAMP(3);
   // main sweep: span descending
   for (int d = L; d >= 0; --d) {
     for (int a = tid; a + d <= L; a += nt) cf_outside_cell(c, a, a + d, FCi, FMi, FM1i, F5i, F5o, FCo, FMo, FM1o, FM2o);
     __syncthreads();
   }
-  // ---- posterior, written in the reference's triangular layout (row i = 0..L, col j = i..L)
-  for (size_t k = tid; k < SZ; k += nt) post[k] = 0.0f;
-  __syncthreads();
-  for (int a = 1; a <= L; ++a)
-    for (int q = a + 1 + tid; q <= L; q += nt) post[off[a] + q] = cf_posterior_cell(c, a, q, FCi, F5i, F5o, FCo, FM1o, Z);
+  CF_STAMP(4);
   if (tid == 0 && B.logz) B.logz[x] = Z;
+}
+
+// posterior: one workgroup per (sequence, row a); fully parallel over pairs
+__global__ __launch_bounds__(CF_THREADS) void k_contrafold_posterior(cf_batch B) {
+  __shared__ cf_params sP;
+  {
+    const float* src = (const float*)B.params;
+    float* dst = (float*)&sP;
+    for (uint32_t k = threadIdx.x; k < sizeof(cf_params) / 4; k += blockDim.x) dst[k] = src[k];
+  }
+  const cf_seq sq = B.seqs[blockIdx.y];
+  const int L = (int)sq.len;
+  const int a = (int)blockIdx.x;  // row 0..L (row 0 and the diagonal stay 0)
+  if (a > L) return;
+  extern __shared__ int s_ints[];
+  for (int k = threadIdx.x; k < CF_INTS(L); k += blockDim.x) s_ints[k] = B.iws[sq.iws_off + k];
+  __syncthreads();
+  cf_ctx c;
+  cf_bind(c, L, s_ints, nullptr, &sP);
+  float* F = B.fws + sq.fws_off;
+  const size_t SZ = (size_t)(L + 1) * (L + 2) / 2;
+  const float *FCi = F, *FCo = F + 3 * SZ, *FM1o = F + 5 * SZ, *F5i = F + 7 * SZ, *F5o = F5i + (L + 1);
+  float* post = B.post + sq.post_off;
+  const float Z = F5i[L];
+  for (int q = a + (int)threadIdx.x; q <= L; q += blockDim.x)
+    post[c.off[a] + q] = (a >= 1 && q > a) ? cf_posterior_cell(c, a, q, FCi, F5i, F5o, FCo, FM1o, Z) : 0.0f;
 }
 
 // dense triangular posterior -> BP rows (i-1) -> (j-1, p) with p > th (fold.cpp:181-188)
@@ -378,9 +510,21 @@ __global__ __launch_bounds__(256) void k_bp_compact(cf_batch B, float th, const 
 
 int contrafold_launch(const cf_batch& B, uint32_t nseq, uint32_t max_len, hipStream_t st) {
   if (!nseq) return DAFS_HIP_OK;
-  const size_t lds = 4 * ((size_t)max_len + 2) * sizeof(int);
-  if (lds > 48 * 1024) return DAFS_HIP_ETOOLONG;
-  hipLaunchKernelGGL(k_contrafold, dim3(nseq), dim3(CF_THREADS), lds, st, B);
+  const size_t ints = (size_t)CF_INTS(max_len) * sizeof(int);
+  const size_t ring = (size_t)CF_RING * (max_len + 1) * sizeof(float);
+  const size_t budget = 100 * 1024;  // dynamic LDS (static: score tables ~11 KB)
+  if (ints > budget) return DAFS_HIP_ETOOLONG;
+  const int use_ring = ints + ring <= budget;
+  const size_t lds = ints + (use_ring ? ring : 0);
+  static bool attr = false;
+  if (!attr) {
+    if (hip_check(hipFuncSetAttribute((const void*)k_contrafold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget))) return DAFS_HIP_ELAUNCH;
+    if (hip_check(hipFuncSetAttribute((const void*)k_contrafold_posterior, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget))) return DAFS_HIP_ELAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k_contrafold, dim3(nseq), dim3(CF_THREADS), lds, st, B, use_ring);
+  if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
+  hipLaunchKernelGGL(k_contrafold_posterior, dim3(max_len + 1, nseq), dim3(CF_THREADS), ints, st, B);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 

@@ -113,6 +113,7 @@ struct dafs_hip_ctx {
   dafs::dev_buf<uint8_t> d_cf_params, cf_seqs, cf_codes;
   dafs::dev_buf<int> cf_iws, cf_cons;
   dafs::dev_buf<float> cf_fws, cf_post, cf_logz;
+  dafs::dev_buf<unsigned long long> cf_stamps;
   // progressive phase workspaces
   dafs::dev_buf<uint8_t> work, work2;
   dafs::dev_buf<dafs::dd_node> d_nodes;
