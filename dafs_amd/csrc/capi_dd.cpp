@@ -2,6 +2,8 @@
 // reference src/fold.h:47-60, src/align.h:57-65) and the fused per-node solver
 // (DAFS::align_alignments + DAFS::solve_by_dd, reference src/dafs.cpp:896-981, 1006-1295).
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -163,12 +165,14 @@ extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs
   if (!mps.valid || !bps.valid || mps.n_tasks != (uint64_t)nseq * (nseq - 1) / 2) return DAFS_HIP_EINVAL;
   dd_params dp;
   dp.w = prm->w; dp.eta0 = prm->eta0; dp.th_a = prm->th_a; dp.th_s = prm->th_s; dp.t_max = prm->t_max; dp.force_iters = prm->force_iters;
+  dp.stamps = getenv("DAFS_HIP_DD_STAMPS") ? 1 : 0;
 
   // ---- host geometry ----
   std::vector<geom> g1(nnodes), g2(nnodes);
   for (uint32_t b = 0; b < nnodes; ++b) {
     const dafs_node_input& ni = in[b];
     if (!ni.n1 || !ni.n2 || !ni.len1 || !ni.len2 || !ni.seq1 || !ni.seq2 || !ni.mask1 || !ni.mask2) return DAFS_HIP_EINVAL;
+    if (ni.len1 > 1024 || ni.len2 > 1023) return DAFS_HIP_ETOOLONG;  // wave DPs: 64 lanes x 16 columns
     int rc;
     if ((rc = make_geom(c, ni.n1, ni.len1, ni.seq1, ni.mask1, g1[b]))) return rc;
     if ((rc = make_geom(c, ni.n2, ni.len2, ni.seq2, ni.mask2, g2[b]))) return rc;
@@ -176,6 +180,7 @@ extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs
 
   // ---- carve workspace A (two passes: size, then pointers) ----
   std::vector<dd_node> nodes(nnodes);
+  size_t lds_max = 0;
   std::vector<region> fills;
   carver cv;
   for (int pass = 0; pass < 2; ++pass) {
@@ -206,6 +211,24 @@ extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs
       carve_nuss(cv, L1, nd.wx);
       carve_nuss(cv, L2, nd.wy);
       nd.dp_z = cv.take<float>(T); nd.tr_z = cv.take<uint8_t>(T);
+      nd.trb_x = cv.take<uint8_t>(XX / 2 + L1 + 16); nd.trb_y = cv.take<uint8_t>(YY / 2 + L2 + 16);
+      nd.s_x = cv.take<float>(((size_t)L1 + 63) * ((L1 + 63) / 64) * 64); nd.s_y = cv.take<float>(((size_t)L2 + 63) * ((L2 + 63) / 64) * 64);
+      nd.pz_s = cv.take<float>(((size_t)L1 + 63) * ((L2 + 64) / 64) * 64); nd.qz_s = cv.take<float>(((size_t)L1 + 63) * ((L2 + 64) / 64) * 64);
+      nd.trk_x = nd.wx.tr; nd.trk_y = nd.wy.tr;  // the L*L uint32 tables double as bifurcation codes; the stack lives in wx.ck / wy.ck
+      {  // LDS plan: previous-row buffers + candidate counters, then traceback tables greedily (alignment, x, y)
+        size_t used = ((size_t)(2 * ((L1 + 63) / 64) + 2 * ((L2 + 63) / 64) + 3 * ((L2 + 64) / 64)) * 64 + L1 + L2) * 4;
+        // the device carves the tables in bit order 0,1,2 then 3,4; they are granted in order of payoff:
+        // the in-flight rows + candidate lists of both folding DPs (bits 3,4), then the traceback tables
+        const size_t need[5] = {(T + 15) & ~(size_t)15, ((size_t)L1 * (L1 + 1) / 2 + 15) & ~(size_t)15, ((size_t)L2 * (L2 + 1) / 2 + 15) & ~(size_t)15,
+                                (size_t)L1 * (64 + 2 * DD_CAP) * 4, (size_t)L2 * (64 + 2 * DD_CAP) * 4};
+        static const int order[5] = {3, 4, 0, 1, 2};
+        nd.lds_flags = 0;
+        for (int o = 0; o < 5; ++o) {
+          const int k = order[o];
+          if (used + need[k] <= kDdLdsBudget) { used += need[k]; nd.lds_flags |= 1u << k; }
+        }
+        lds_max = std::max(lds_max, used);
+      }
       nd.env = cv.take<uint32_t>(2 * ((size_t)L1 + 1));
       nd.px_ptr = cv.take<uint32_t>((size_t)L1 + 2); nd.px_j = cv.take<uint32_t>(XX / 2 + 2);
       nd.py_ptr = cv.take<uint32_t>((size_t)L2 + 2); nd.py_l = cv.take<uint32_t>(YY / 2 + 2);
@@ -214,7 +237,7 @@ extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs
       nd.cbp_cnt = cv.take<uint32_t>(XX / 2 + 2);
       nd.tx = cv.take<int32_t>(XX / 2 + 2); nd.ty = cv.take<int32_t>(YY / 2 + 2); nd.tz = cv.take<int32_t>(ZZ + 1);
       nd.x = cv.take<uint32_t>((size_t)L1 + 2); nd.y = cv.take<uint32_t>((size_t)L2 + 2); nd.z = cv.take<uint32_t>((size_t)L1 + 2);
-      nd.score = cv.take<float>(1); nd.info = cv.take<uint32_t>(4);
+      nd.score = cv.take<float>(1); nd.info = cv.take<uint32_t>(16);
     }
     if (pass == 0) {
       int rc = c->work.reserve(cv.used + 256);
@@ -264,7 +287,7 @@ extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs
   }
   if ((rc = c->d_nodes.upload(nodes.data(), nnodes, c->stream))) return rc;
   if ((rc = dd_cbp_fill_launch(c->d_nodes.ptr, nnodes, dp, c->stream))) return rc;
-  if ((rc = dd_solve_launch(c->d_nodes.ptr, nnodes, dp, c->stream))) return rc;
+  if ((rc = dd_solve_launch(c->d_nodes.ptr, nnodes, dp, lds_max, c->stream))) return rc;
   // ---- results ----
   std::vector<float> score(nnodes);
   for (uint32_t b = 0; b < nnodes; ++b) {
@@ -277,6 +300,14 @@ extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs
     if (!ok) return DAFS_HIP_ELAUNCH;
   }
   if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
+  if (dp.stamps) {
+    for (uint32_t b = 0; b < nnodes; ++b) {
+      uint32_t tk[16];
+      if (hip_check(hipMemcpy(tk, nodes[b].info, sizeof tk, hipMemcpyDeviceToHost))) break;
+      fprintf(stderr, "dd node L1=%u L2=%u n=%u+%u ncbp=%u iters=%u | us: x-dp %.0f x-traceback %.0f wait %.0f cbp %.0f update %.0f tail %.0f\n", nodes[b].L1,
+              nodes[b].L2, nodes[b].n1, nodes[b].n2, tk[0], tk[1], tk[8] / 100.0, tk[9] / 100.0, tk[10] / 100.0, tk[11] / 100.0, tk[12] / 100.0, tk[13] / 100.0);
+    }
+  }
   for (uint32_t b = 0; b < nnodes; ++b) {
     out[b].score = score[b];
     out[b].ncbp = info[4 * (size_t)b];

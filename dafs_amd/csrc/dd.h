@@ -24,7 +24,12 @@ struct dd_node {
   float *p_x, *p_y, *p_z, *q_x, *q_y, *q_z;
   nuss_ws wx, wy;
   float* dp_z;        // (L1+1)*(L2+1)
-  uint8_t* tr_z;      // (L1+1)*(L2+1)
+  uint8_t* tr_z;      // (L1+1)*(L2+1)   traceback codes of the alignment DP (HBM copy, used when it does not fit LDS)
+  uint8_t *trb_x, *trb_y;   // L(L+1)/2 each: Nussinov traceback codes 0..4 (HBM copies)
+  uint32_t *trk_x, *trk_y;  // L*L each: bifurcation code of the cells whose traceback code is 4
+  float *s_x, *s_y;         // (L+63)*ceil(L/64)*64 each: pair scores w*(p-th)-q in sweep order of the folding DP
+  float *pz_s, *qz_s;       // (L1+63)*ceil((L2+1)/64)*64 each: p_z, q_z in sweep order of the alignment DP
+  uint32_t lds_flags;       // which traceback tables live in LDS: bit 0 alignment, bit 1 x, bit 2 y
   uint32_t* env;      // 2*(L1+1)
   // sparse structure of p_x / p_y / p_z (> CUTOFF) and of the consensus base pairs
   int32_t *xmap, *ymap, *zmap;    // dense cell -> entry id (px / py / cz lists) or -1
@@ -38,19 +43,22 @@ struct dd_node {
   // results
   uint32_t *x, *y, *z;
   float* score;                   // [1]
-  uint32_t* info;                 // [4]: ncbp, iterations, violated, status
+  uint32_t* info;                 // [16]: ncbp, iterations, violated, status; [8..13] optional phase ticks
 };
 
 struct dd_params {
   float w, eta0, th_a, th_s;
   uint32_t t_max;
   int force_iters;
+  int stamps;  // accumulate per-phase timing into info[8..13] (tuning aid)
 };
 
 int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, mp_store_dev mp, bp_store_dev bp, hipStream_t st);
 int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st);
 int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st);
-int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st);
+#define DD_CAP 4  // candidates per column kept in LDS by the fast folding DP
+static const size_t kDdLdsBudget = 150 * 1024;  // dynamic LDS of k_dd_solve
+int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, hipStream_t st);
 // standalone decoders on dense device matrices (one workgroup each)
 int nussinov_launch(uint32_t L, const float* p, const float* q, float w, float th, nuss_ws ws, uint32_t* ss, float* score, hipStream_t st);
 int nw_launch(uint32_t L1, uint32_t L2, const float* p, const float* q, float th, uint32_t* env, int compute_env,
