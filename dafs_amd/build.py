@@ -17,6 +17,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the reference CPU build has no FMA contraction; bit-exact parity needs the same.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall",
          "-Wno-unused-function", "-Wno-missing-braces", "-fno-fast-math"]
+FLAGS += os.environ.get("DAFS_HIP_EXTRA_FLAGS", "").split()  # tuning experiments only
 
 
 def sources():

@@ -217,13 +217,13 @@ extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs
       nd.trk_x = nd.wx.tr; nd.trk_y = nd.wy.tr;  // the L*L uint32 tables double as bifurcation codes; the stack lives in wx.ck / wy.ck
       {  // LDS plan: previous-row buffers + candidate counters, then traceback tables greedily (alignment, x, y)
         size_t used = ((size_t)(2 * ((L1 + 63) / 64) + 2 * ((L2 + 63) / 64) + 3 * ((L2 + 64) / 64)) * 64 + L1 + L2) * 4;
-        // the device carves the tables in bit order 0,1,2 then 3,4; they are granted in order of payoff:
-        // the in-flight rows + candidate lists of both folding DPs (bits 3,4), then the traceback tables
-        const size_t need[5] = {(T + 15) & ~(size_t)15, ((size_t)L1 * (L1 + 1) / 2 + 15) & ~(size_t)15, ((size_t)L2 * (L2 + 1) / 2 + 15) & ~(size_t)15,
-                                (size_t)L1 * (64 + 2 * DD_CAP) * 4, (size_t)L2 * (64 + 2 * DD_CAP) * 4};
-        static const int order[5] = {3, 4, 0, 1, 2};
+        // granted in order of payoff: the fast x and y folding DPs (bits 1, 2: packed traceback nibbles, the 64
+        // rows in flight, DD_CAP candidates per column), then the packed alignment traceback (bit 0)
+        const size_t need[3] = {(((size_t)T + 15) / 16) * 4, (((size_t)L1 * (L1 + 1) / 2 + 7) / 8 + (size_t)L1 * (64 + DD_CAP)) * 4,
+                                (((size_t)L2 * (L2 + 1) / 2 + 7) / 8 + (size_t)L2 * (64 + DD_CAP)) * 4};
+        static const int order[3] = {1, 2, 0};
         nd.lds_flags = 0;
-        for (int o = 0; o < 5; ++o) {
+        for (int o = 0; o < 3; ++o) {
           const int k = order[o];
           if (used + need[k] <= kDdLdsBudget) { used += need[k]; nd.lds_flags |= 1u << k; }
         }
@@ -304,8 +304,8 @@ extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs
     for (uint32_t b = 0; b < nnodes; ++b) {
       uint32_t tk[16];
       if (hip_check(hipMemcpy(tk, nodes[b].info, sizeof tk, hipMemcpyDeviceToHost))) break;
-      fprintf(stderr, "dd node L1=%u L2=%u n=%u+%u ncbp=%u iters=%u | us: x-dp %.0f x-traceback %.0f wait %.0f cbp %.0f update %.0f tail %.0f\n", nodes[b].L1,
-              nodes[b].L2, nodes[b].n1, nodes[b].n2, tk[0], tk[1], tk[8] / 100.0, tk[9] / 100.0, tk[10] / 100.0, tk[11] / 100.0, tk[12] / 100.0, tk[13] / 100.0);
+      fprintf(stderr, "dd node L1=%u L2=%u n=%u+%u ncbp=%u iters=%u slow-xy=%u+%u | us: x-dp %.0f x-traceback %.0f wait %.0f cbp %.0f update %.0f tail %.0f\n", nodes[b].L1,
+              nodes[b].L2, nodes[b].n1, nodes[b].n2, tk[0], tk[1], tk[4], tk[5], tk[8] / 100.0, tk[9] / 100.0, tk[10] / 100.0, tk[11] / 100.0, tk[12] / 100.0, tk[13] / 100.0);
     }
   }
   for (uint32_t b = 0; b < nnodes; ++b) {

@@ -29,7 +29,7 @@ struct dd_node {
   uint32_t *trk_x, *trk_y;  // L*L each: bifurcation code of the cells whose traceback code is 4
   float *s_x, *s_y;         // (L+63)*ceil(L/64)*64 each: pair scores w*(p-th)-q in sweep order of the folding DP
   float *pz_s, *qz_s;       // (L1+63)*ceil((L2+1)/64)*64 each: p_z, q_z in sweep order of the alignment DP
-  uint32_t lds_flags;       // which traceback tables live in LDS: bit 0 alignment, bit 1 x, bit 2 y
+  uint32_t lds_flags;       // LDS plan: bit 0 packed alignment traceback, bit 1 / bit 2 fast form of the x / y folding DP
   uint32_t* env;      // 2*(L1+1)
   // sparse structure of p_x / p_y / p_z (> CUTOFF) and of the consensus base pairs
   int32_t *xmap, *ymap, *zmap;    // dense cell -> entry id (px / py / cz lists) or -1
@@ -57,7 +57,7 @@ int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, mp_store_dev mp, bp_s
 int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st);
 int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st);
 #define DD_CAP 4  // candidates per column kept in LDS by the fast folding DP
-static const size_t kDdLdsBudget = 150 * 1024;  // dynamic LDS of k_dd_solve
+static const size_t kDdLdsBudget = 156 * 1024;  // dynamic LDS of k_dd_solve (the CU has 160 KB; ~2.2 KB is static)
 int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, hipStream_t st);
 // standalone decoders on dense device matrices (one workgroup each)
 int nussinov_launch(uint32_t L, const float* p, const float* q, float w, float th, nuss_ws ws, uint32_t* ss, float* score, hipStream_t st);

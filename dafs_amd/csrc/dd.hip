@@ -190,6 +190,25 @@ __device__ bool nw_traceback(uint32_t L1, uint32_t L2, const uint8_t* tr, uint32
   return i == 0 && k == 0;
 }
 
+// the same walk over the two-bit table of nw_wave_reg<W, true>; row 0 / column 0 are implicit
+__device__ bool nw_traceback_packed(uint32_t L1, uint32_t L2, const uint32_t* tr_, uint32_t* al) {
+  const __attribute__((address_space(3))) uint32_t* tr = (const __attribute__((address_space(3))) uint32_t*)tr_;
+  const uint32_t W = L2 + 1;
+  int i = (int)L1, k = (int)L2;
+  uint32_t guard = L1 + L2 + 2;
+  while ((i > 0 || k > 0) && guard--) {
+    uint32_t t;
+    if (i == 0) t = 3;
+    else if (k == 0) t = 2;
+    else { const uint32_t q = (uint32_t)i * W + k; t = (tr[q >> 4] >> ((q & 15u) * 2)) & 3u; }
+    if (t == 1) { al[i - 1] = (uint32_t)(k - 1); --i; --k; }
+    else if (t == 2) { al[i - 1] = DD_NONE; --i; }
+    else if (t == 3) { --k; }
+    else return false;
+  }
+  return i == 0 && k == 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // Single-wavefront forms of the two DPs, used inside the subgradient loop.  Lane t owns W
 // consecutive columns and keeps the previous row of its columns in LDS (P[c*64+lane]); rows are
@@ -279,95 +298,47 @@ __device__ float nuss_wave(uint32_t L, const float* __restrict__ S, const nuss_w
   return __shfl(score, (int)((L - 1) / W));
 }
 
-// The same DP with everything on the per-cell dependency chain in LDS: `ring` holds the 64 rows in
-// flight (row i at slot i & 63; a row is live for exactly the 64 steps its lanes sweep it), and the
-// first DD_CAP candidates of every column sit in lck/lcv (the rest spill to ws.ck / ws.cv).
-__device__ float nuss_wave_lds(uint32_t L, const float* __restrict__ S, const nuss_ws& ws, uint8_t* trb, uint32_t* trk, float* P, float* Sb,
-                               uint32_t* cc, float* ring, uint32_t* lck, float* lcv, int lane) {
-  const uint32_t W = (L + 63) / 64;
-  for (uint32_t c = 0; c < W; ++c) {
-    P[c * 64 + lane] = 0.0f;
-    Sb[c * 64 + lane] = 0.0f;
-    const uint32_t j = lane * W + c;
-    if (j < L) cc[j] = 0;
-  }
-  float last = 0.0f, leftprev = 0.0f, score = 0.0f;
-  const int nsteps = (int)L + 63;
-  for (uint32_t c = 0; c < W; ++c) Sb[c * 64 + lane] = S[(size_t)c * 64 + lane];  // step 0
-  for (int s = 0; s < nsteps; ++s) {
-    const int i = (int)L - 1 - (s - lane);
-    const bool rowv = i >= 0 && i < (int)L;
-    // prefetch the scores of the next step (coalesced: S is stored in sweep order)
-    float nxt[DD_WMAX];
-    const bool nv = s + 1 < nsteps;
-#pragma unroll
-    for (int c = 0; c < DD_WMAX; ++c) nxt[c] = (nv && (uint32_t)c < W) ? S[((size_t)(s + 1) * W + c) * 64 + lane] : 0.0f;
-    float recv = __shfl_up(last, 1);
-    if (lane == 0) recv = 0.0f;
-    float diag = leftprev;
-    float left = recv;
-    float v = 0.0f;
-    float* rrow = ring + (size_t)((uint32_t)i & 63u) * L;
-    for (uint32_t c = 0; c < W; ++c) {
-      const uint32_t j = lane * W + c;
-      const float below = P[c * 64 + lane];
-      v = 0.0f;
-      if (rowv && j < L && (int)j > i) {
-        const uint32_t ui = (uint32_t)i;
-        uint32_t t = 0;
-        if (ui + 1 < j) { v = below; t = 1; }
-        if (ui < j - 1 && v < left) { v = left; t = 2; }
-        const uint32_t n = cc[j];
-        if (ui + 1 < j - 1) {
-          const float sc = Sb[c * 64 + lane];
-          if (sc > 0.0f) {
-            const float cand = diag + sc;
-            if (n < DD_CAP) { lck[n * L + j] = ui; lcv[n * L + j] = cand; }
-            else { ws.ck[(size_t)j * L + n] = ui; ws.cv[(size_t)j * L + n] = cand; }
-            cc[j] = n + 1;
-            if (v < cand) { v = cand; t = 3; }
-          }
-        }
-        for (uint32_t x = 0; x < n; ++x) {
-          uint32_t k; float cvv;
-          if (x < DD_CAP) { k = lck[x * L + j]; cvv = lcv[x * L + j]; }
-          else { k = ws.ck[(size_t)j * L + x]; cvv = ws.cv[(size_t)j * L + x]; }
-          const float dik = (k - 1 == ui) ? 0.0f : rrow[k - 1];
-          const float cand = dik + cvv;
-          if (v < cand) { v = cand; t = k - ui + 3; }
-        }
-        rrow[j] = v;
-        trb[tri_index(L, ui, j)] = (uint8_t)(t < 4 ? t : 4);
-        if (t >= 4) trk[(size_t)ui * L + j] = t;
-        if (ui == 0 && j == L - 1) score = v;
-      }
-      diag = below;
-      P[c * 64 + lane] = v;
-      left = v;
-    }
-    leftprev = recv;
-    last = v;
-#pragma unroll
-    for (int c = 0; c < DD_WMAX; ++c)
-      if ((uint32_t)c < W) Sb[c * 64 + lane] = nxt[c];
-  }
-  return __shfl(score, (int)((L - 1) / W));
-}
-
 // Register-resident forms for W <= DD_WREG columns per lane (W a template constant): the previous
 // row, the scores and the candidate counters of the lane's columns live in registers, so a cell
 // without candidates touches LDS only to publish its value; a cell with candidates makes two LDS
 // round trips (all candidate keys/values at once, then all dp[i][k-1] at once).
 #define DD_WREG 8
+// Address-space-qualified views: the loops below must compile to ds_* / global_* instructions, not
+// flat_* ones (a flat access waits on both counters, i.e. on the prefetch of the next step as well).
+#define DD_LDS __attribute__((address_space(3)))
+#define DD_GLB __attribute__((address_space(1)))
+// The loop must not contain a global store either: on gfx9 loads and stores share vmcnt and complete
+// out of order with each other, so one possible store in flight turns every wait into vmcnt(0) and
+// the prefetch of the next step is waited for at once.  Hence: traceback codes in LDS (a bifurcation
+// is recorded as 4 + its candidate slot, the split row is read back from lck), and a column that
+// collects more than DD_CAP candidates raises `ovf`; the caller then repeats the DP with
+// nuss_wave, which works in global memory.
 template <int W>
-__device__ float nuss_wave_reg(uint32_t L, const float* __restrict__ S, const nuss_ws& ws, uint8_t* trb, uint32_t* trk, float* ring,
-                               uint32_t* lck, float* lcv, int lane) {
-  float P[W], Sc[W], nx[W];
-  uint32_t n[W];
+__device__ float nuss_wave_reg(uint32_t L, const float* S_, uint32_t* trb_, float* ring_, uint32_t* lck_, int lane, bool* ovf_out) {
+  DD_GLB const float* S = (DD_GLB const float*)S_;
+  DD_LDS char* ring = (DD_LDS char*)ring_;
+  DD_LDS uint32_t* lck = (DD_LDS uint32_t*)lck_;
+  DD_LDS uint32_t* trb = (DD_LDS uint32_t*)trb_;  // one nibble per cell of the upper triangle, zeroed by the caller
+  // Per owned column: previous row, score, and the column's candidates as a shift register (slot 0 =
+  // newest; empty slots hold -inf so they never win): value dp[k+1][j-1]+s and the byte offset of
+  // dp[.][k-1] within a row of the ring.  The whole cell is straight-line selects: the lanes of a
+  // wavefront are on different rows and columns, so a branch would be taken by somebody anyway.
+  float P[W], Sc[W], nx[W], cvs[W][DD_CAP];
+  uint32_t koff[W][DD_CAP], n[W];
 #pragma unroll
-  for (int c = 0; c < W; ++c) { P[c] = 0.0f; n[c] = 0; Sc[c] = S[(size_t)c * 64 + lane]; nx[c] = 0.0f; }
+  for (int c = 0; c < W; ++c) {
+    P[c] = 0.0f; n[c] = 0; Sc[c] = S[(size_t)c * 64 + lane]; nx[c] = 0.0f;
+#pragma unroll
+    for (int x = 0; x < DD_CAP; ++x) { cvs[c][x] = -INFINITY; koff[c][x] = 0; }
+  }
+  // land the first step's scores before the loop: a load still pending at the loop header makes the
+  // compiler wait with vmcnt(0) at the first use inside the loop, i.e. for the prefetch just issued
+#pragma unroll
+  for (int c = 0; c < W; ++c) asm volatile("" : "+v"(Sc[c]));
   float last = 0.0f, leftprev = 0.0f, score = 0.0f;
+  bool ovf = false;
   const int nsteps = (int)L + 63;
+  const int j0 = lane * W;
   for (int s = 0; s < nsteps; ++s) {
     const int i = (int)L - 1 - (s - lane);
     const bool rowv = i >= 0 && i < (int)L;
@@ -379,84 +350,119 @@ __device__ float nuss_wave_reg(uint32_t L, const float* __restrict__ S, const nu
     if (lane == 0) recv = 0.0f;
     float diag = leftprev;
     float left = recv;
-    float v = 0.0f;
     const uint32_t ui = (uint32_t)i;
-    float* rrow = ring + (size_t)(ui & 63u) * L;
+    DD_LDS char* rrow = ring + (ui & 63u) * (L * 4);
+    const uint32_t tbase = rowv ? (uint32_t)tri_index(L, ui, ui) : 0u;  // + (j - i)
+    const int d0 = j0 - i;
+    if (rowv && (uint32_t)(i - j0) < (uint32_t)W) *(DD_LDS float*)(rrow + ui * 4) = 0.0f;  // dp[i][i], read by candidates of row i+1
+    const bool row0 = rowv && i == 0;
+    const uint32_t knew = ui ? (ui - 1) * 4 : 0u;
 #pragma unroll
     for (int c = 0; c < W; ++c) {
-      const uint32_t j = lane * W + c;
+      const int j = j0 + c, d = d0 + c;
+      const bool valid = rowv && j < (int)L && d >= 1;
       const float below = P[c];
-      v = 0.0f;
-      if (rowv && j < L && (int)j > i) {
-        uint32_t t = 0;
-        if (ui + 1 < j) { v = below; t = 1; }
-        if (ui < j - 1 && v < left) { v = left; t = 2; }
-        const uint32_t nc = n[c];
-        if (ui + 1 < j - 1) {
-          const float sc = Sc[c];
-          if (sc > 0.0f) {
-            const float cand = diag + sc;
-            if (nc < DD_CAP) { lck[nc * L + j] = ui; lcv[nc * L + j] = cand; }
-            else { ws.ck[(size_t)j * L + nc] = ui; ws.cv[(size_t)j * L + nc] = cand; }
-            n[c] = nc + 1;
-            if (v < cand) { v = cand; t = 3; }
-          }
-        }
-        if (nc) {
-          uint32_t kk[DD_CAP];
-          float cvs[DD_CAP], dk[DD_CAP];
+      const bool m1 = d >= 2;                      // nussinov.cpp:226-233
+      float v = m1 ? below : 0.0f;
+      uint32_t t = m1 ? 1u : 0u;
+      const bool m2 = m1 && v < left;
+      v = m2 ? left : v; t = m2 ? 2u : t;
+      const float cand = diag + Sc[c];             // :236
+      const bool create = valid && d >= 3 && Sc[c] > 0.0f;
+      const bool m3 = create && v < cand;
+      v = m3 ? cand : v; t = m3 ? 3u : t;
+      const uint32_t nc = n[c];
+      float dk[DD_CAP];
 #pragma unroll
-          for (int x = 0; x < DD_CAP; ++x) { kk[x] = lck[x * L + j]; cvs[x] = lcv[x * L + j]; }
+      for (int x = 0; x < DD_CAP; ++x) dk[x] = *(DD_LDS const float*)(rrow + koff[c][x]);  // all dp[i][k-1] in one round trip
 #pragma unroll
-          for (int x = 0; x < DD_CAP; ++x) dk[x] = rrow[(uint32_t)x < nc ? kk[x] - 1 : 0u];
-#pragma unroll
-          for (int x = 0; x < DD_CAP; ++x)
-            if ((uint32_t)x < nc) {
-              const float dik = (kk[x] - 1 == ui) ? 0.0f : dk[x];  // dp[i][i] = 0 is never stored
-              const float cand = dik + cvs[x];
-              if (v < cand) { v = cand; t = kk[x] - ui + 3; }
-            }
-          for (uint32_t x = DD_CAP; x < nc; ++x) {
-            const uint32_t k = ws.ck[(size_t)j * L + x];
-            const float dik = (k - 1 == ui) ? 0.0f : rrow[k - 1];
-            const float cand = dik + ws.cv[(size_t)j * L + x];
-            if (v < cand) { v = cand; t = k - ui + 3; }
-          }
-        }
-        rrow[j] = v;
-        trb[tri_index(L, ui, j)] = (uint8_t)(t < 4 ? t : 4);
-        if (t >= 4) trk[(size_t)ui * L + j] = t;
-        if (ui == 0 && j == L - 1) score = v;
+      for (int x = DD_CAP - 1; x >= 0; --x) {      // bifurcations, oldest candidate first (:245-255)
+        const float cx = dk[x] + cvs[c][x];
+        const bool m = v < cx;
+        v = m ? cx : v; t = m ? (uint32_t)(4 + x) : t;
       }
+      t = t >= 4 ? nc + 7 - t : t;                 // slot -> 4 + insertion index
+      if (valid) {
+        *(DD_LDS float*)(rrow + j * 4) = v;
+        const uint32_t q = tbase + (uint32_t)d;
+        __hip_atomic_fetch_or(&trb[q >> 3], t << ((q & 7u) * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (create) {
+        if (nc < DD_CAP) lck[nc * L + j] = ui; else ovf = true;
+      }
+      n[c] = (create && nc < DD_CAP) ? nc + 1 : nc;
+#pragma unroll
+      for (int x = DD_CAP - 1; x >= 1; --x) { cvs[c][x] = create ? cvs[c][x - 1] : cvs[c][x]; koff[c][x] = create ? koff[c][x - 1] : koff[c][x]; }
+      cvs[c][0] = create ? cand : cvs[c][0];
+      koff[c][0] = create ? knew : koff[c][0];
+      v = valid ? v : 0.0f;
+      if (row0 && j == (int)L - 1) score = v;
       diag = below;
       P[c] = v;
       left = v;
     }
     leftprev = recv;
-    last = v;
+    last = left;
 #pragma unroll
     for (int c = 0; c < W; ++c) Sc[c] = nx[c];
   }
+  *ovf_out = __any(ovf);
   return __shfl(score, (int)((L - 1) / W));
 }
 
-__device__ float nuss_wave_fast(uint32_t W, uint32_t L, const float* __restrict__ S, const nuss_ws& ws, uint8_t* trb, uint32_t* trk, float* ring,
-                                uint32_t* lck, float* lcv, int lane) {
+__device__ __noinline__ float nuss_wave_fast(uint32_t W, uint32_t L, const float* S, uint32_t* trb, float* ring, uint32_t* lck, int lane, bool* ovf) {
   switch (W) {
-    case 1: return nuss_wave_reg<1>(L, S, ws, trb, trk, ring, lck, lcv, lane);
-    case 2: return nuss_wave_reg<2>(L, S, ws, trb, trk, ring, lck, lcv, lane);
-    case 3: return nuss_wave_reg<3>(L, S, ws, trb, trk, ring, lck, lcv, lane);
-    case 4: return nuss_wave_reg<4>(L, S, ws, trb, trk, ring, lck, lcv, lane);
-    case 5: return nuss_wave_reg<5>(L, S, ws, trb, trk, ring, lck, lcv, lane);
-    case 6: return nuss_wave_reg<6>(L, S, ws, trb, trk, ring, lck, lcv, lane);
-    case 7: return nuss_wave_reg<7>(L, S, ws, trb, trk, ring, lck, lcv, lane);
-    default: return nuss_wave_reg<8>(L, S, ws, trb, trk, ring, lck, lcv, lane);
+    case 1: return nuss_wave_reg<1>(L, S, trb, ring, lck, lane, ovf);
+    case 2: return nuss_wave_reg<2>(L, S, trb, ring, lck, lane, ovf);
+    case 3: return nuss_wave_reg<3>(L, S, trb, ring, lck, lane, ovf);
+    case 4: return nuss_wave_reg<4>(L, S, trb, ring, lck, lane, ovf);
+    case 5: return nuss_wave_reg<5>(L, S, trb, ring, lck, lane, ovf);
+    case 6: return nuss_wave_reg<6>(L, S, trb, ring, lck, lane, ovf);
+    case 7: return nuss_wave_reg<7>(L, S, trb, ring, lck, lane, ovf);
+    default: return nuss_wave_reg<8>(L, S, trb, ring, lck, lane, ovf);
   }
 }
 
-template <int W>
-__device__ float nw_wave_reg(uint32_t L1, uint32_t L2, const float* __restrict__ ps, const float* __restrict__ qs, float th,
-                             const uint32_t* __restrict__ env, uint8_t* tr, int lane) {
+// traceback of nuss_wave_reg's codes (see nuss_traceback_b for the walk)
+__device__ void nuss_traceback_fast(uint32_t L, uint32_t* trb_, uint32_t* lck_, uint32_t* ss_, uint32_t* stack_) {
+  DD_LDS const uint32_t* trb = (DD_LDS const uint32_t*)trb_;
+  DD_LDS const uint32_t* lck = (DD_LDS const uint32_t*)lck_;
+  DD_LDS uint32_t* stack = (DD_LDS uint32_t*)stack_;
+  DD_GLB uint32_t* ss = (DD_GLB uint32_t*)ss_;
+  uint32_t sp = 0;
+  int i = 0, j = (int)L - 1;
+  uint32_t guard = 4 * L + 8;
+  while (guard--) {
+    uint32_t t = 0;
+    if (j > i) {
+      const uint32_t q = (uint32_t)tri_index(L, (uint32_t)i, (uint32_t)j);
+      t = (trb[q >> 3] >> ((q & 7u) * 4)) & 15u;
+    }
+    if (t == 0) {
+      if (!sp) break;
+      const uint32_t e = stack[--sp];
+      i = (int)(e >> 16); j = (int)(e & 0xFFFFu);
+      continue;
+    }
+    if (t == 1) ++i;
+    else if (t == 2) --j;
+    else if (t == 3) { ss[i] = j; ++i; --j; }
+    else {
+      const int k = (int)lck[(t - 4) * L + j];
+      ss[k] = j;
+      if (k - 1 > i) stack[sp++] = ((uint32_t)i << 16) | (uint32_t)(k - 1);
+      i = k + 1; --j;
+    }
+  }
+}
+
+template <int W, bool TRL>
+__device__ float nw_wave_reg(uint32_t L1, uint32_t L2, const float* ps_, const float* qs_, float th, const uint32_t* env_, uint8_t* tr_, int lane) {
+  DD_GLB const float* ps = (DD_GLB const float*)ps_;
+  DD_GLB const float* qs = (DD_GLB const float*)qs_;
+  DD_GLB const uint32_t* env = (DD_GLB const uint32_t*)env_;
+  DD_LDS uint32_t* tr_l = (DD_LDS uint32_t*)tr_;  // TRL: two bits per cell (1 M, 2 X, 3 Y), zeroed by the caller
+  DD_GLB uint8_t* tr_g = (DD_GLB uint8_t*)tr_;
   const uint32_t T = L2 + 1;
   float P[W], Pc[W], Qc[W], np[W], nq[W];
 #pragma unroll
@@ -465,6 +471,9 @@ __device__ float nw_wave_reg(uint32_t L1, uint32_t L2, const float* __restrict__
   const int nsteps = (int)L1 + 63;
   uint32_t ef = 1u, es = 0u;
   if (lane == 0) { ef = env[2]; es = env[3]; }  // row 1
+#pragma unroll
+  for (int c = 0; c < W; ++c) asm volatile("" : "+v"(Pc[c]), "+v"(Qc[c]));  // nothing pending at the loop header (see nuss_wave_reg)
+  asm volatile("" : "+v"(ef), "+v"(es));
   for (int s = 0; s < nsteps; ++s) {
     const int i = s - lane + 1;
     const bool rowv = i >= 1 && i <= (int)L1;
@@ -488,10 +497,13 @@ __device__ float nw_wave_reg(uint32_t L1, uint32_t L2, const float* __restrict__
         else if (k >= ef && k <= es) {
           v = diag + Pc[c] - th;
           v = v + Qc[c];
-          uint8_t t = 'M';
-          if (v < up) { v = up; t = 'X'; }
-          if (v < left) { v = left; t = 'Y'; }
-          tr[(size_t)i * T + k] = t;
+          uint32_t t = 1;
+          if (v < up) { v = up; t = 2; }
+          if (v < left) { v = left; t = 3; }
+          if (TRL) {
+            const uint32_t q = (uint32_t)i * T + k;
+            __hip_atomic_fetch_or(&tr_l[q >> 4], t << ((q & 15u) * 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else tr_g[(size_t)i * T + k] = t == 1 ? 'M' : (t == 2 ? 'X' : 'Y');
         } else v = -FLT_MAX;
         if (i == (int)L1 && k == L2) score = v;
       }
@@ -508,17 +520,17 @@ __device__ float nw_wave_reg(uint32_t L1, uint32_t L2, const float* __restrict__
   return __shfl(score, (int)(L2 / W));
 }
 
-__device__ float nw_wave_fast(uint32_t W, uint32_t L1, uint32_t L2, const float* __restrict__ ps, const float* __restrict__ qs, float th,
-                              const uint32_t* __restrict__ env, uint8_t* tr, int lane) {
+template <bool TRL>
+__device__ __noinline__ float nw_wave_fast(uint32_t W, uint32_t L1, uint32_t L2, const float* ps, const float* qs, float th, const uint32_t* env, uint8_t* tr, int lane) {
   switch (W) {
-    case 1: return nw_wave_reg<1>(L1, L2, ps, qs, th, env, tr, lane);
-    case 2: return nw_wave_reg<2>(L1, L2, ps, qs, th, env, tr, lane);
-    case 3: return nw_wave_reg<3>(L1, L2, ps, qs, th, env, tr, lane);
-    case 4: return nw_wave_reg<4>(L1, L2, ps, qs, th, env, tr, lane);
-    case 5: return nw_wave_reg<5>(L1, L2, ps, qs, th, env, tr, lane);
-    case 6: return nw_wave_reg<6>(L1, L2, ps, qs, th, env, tr, lane);
-    case 7: return nw_wave_reg<7>(L1, L2, ps, qs, th, env, tr, lane);
-    default: return nw_wave_reg<8>(L1, L2, ps, qs, th, env, tr, lane);
+    case 1: return nw_wave_reg<1, TRL>(L1, L2, ps, qs, th, env, tr, lane);
+    case 2: return nw_wave_reg<2, TRL>(L1, L2, ps, qs, th, env, tr, lane);
+    case 3: return nw_wave_reg<3, TRL>(L1, L2, ps, qs, th, env, tr, lane);
+    case 4: return nw_wave_reg<4, TRL>(L1, L2, ps, qs, th, env, tr, lane);
+    case 5: return nw_wave_reg<5, TRL>(L1, L2, ps, qs, th, env, tr, lane);
+    case 6: return nw_wave_reg<6, TRL>(L1, L2, ps, qs, th, env, tr, lane);
+    case 7: return nw_wave_reg<7, TRL>(L1, L2, ps, qs, th, env, tr, lane);
+    default: return nw_wave_reg<8, TRL>(L1, L2, ps, qs, th, env, tr, lane);
   }
 }
 
@@ -792,7 +804,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes,
   nw_envelope(L1, L2, nd.p_z, prm.th_a, nd.env, nd.x, nd.z);  // x / z double as scratch here
   nw_init(L1, L2, nd.dp_z, nd.tr_z);
   __syncthreads();
-  if (tid == 0) { nd.info[0] = s_total; nd.info[1] = 0; nd.info[2] = 0; nd.info[3] = 0; }
+  if (tid == 0) { nd.info[0] = s_total; nd.info[1] = 0; nd.info[2] = 0; nd.info[3] = 0; nd.info[4] = 0; nd.info[5] = 0; }
 }
 
 __global__ __launch_bounds__(DD_THREADS) void k_node_cbp_fill(const dd_node* nodes, dd_params prm) {
@@ -892,17 +904,20 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
   uint32_t* ccx = (uint32_t*)(Qbz + Wz * 64);
   uint32_t* ccy = ccx + L1;
   unsigned char* lds_tail = (unsigned char*)(ccy + L2);
-  const size_t nz = (size_t)(L1 + 1) * (L2 + 1), nx = (size_t)L1 * (L1 + 1) / 2, ny = (size_t)L2 * (L2 + 1) / 2;
-  uint8_t* trz = nd.tr_z;
-  uint8_t* trx = nd.trb_x;
-  uint8_t* try_ = nd.trb_y;
-  if (nd.lds_flags & 1) { trz = lds_tail; lds_tail += (nz + 15) & ~(size_t)15; }
-  if (nd.lds_flags & 2) { trx = lds_tail; lds_tail += (nx + 15) & ~(size_t)15; }
-  if (nd.lds_flags & 4) { try_ = lds_tail; lds_tail += (ny + 15) & ~(size_t)15; }
-  float *ringx = nullptr, *ringy = nullptr, *lcvx = nullptr, *lcvy = nullptr;
+  // bit 0: packed alignment traceback; bit 1 / bit 2: the fast form of the x / y folding DP
+  // (in-flight rows, candidate lists and packed traceback codes)
+  const uint32_t nzw = (uint32_t)(((size_t)(L1 + 1) * (L2 + 1) + 15) / 16), nxw = (uint32_t)(((size_t)L1 * (L1 + 1) / 2 + 7) / 8),
+                 nyw = (uint32_t)(((size_t)L2 * (L2 + 1) / 2 + 7) / 8);
+  uint32_t *trzp = nullptr, *trxp = nullptr, *tryp = nullptr;
+  float *ringx = nullptr, *ringy = nullptr;
   uint32_t *lckx = nullptr, *lcky = nullptr;
-  if (nd.lds_flags & 8) { ringx = (float*)lds_tail; lckx = (uint32_t*)(ringx + 64 * (size_t)L1); lcvx = (float*)(lckx + DD_CAP * (size_t)L1); lds_tail = (unsigned char*)(lcvx + DD_CAP * (size_t)L1); }
-  if (nd.lds_flags & 16) { ringy = (float*)lds_tail; lcky = (uint32_t*)(ringy + 64 * (size_t)L2); lcvy = (float*)(lcky + DD_CAP * (size_t)L2); lds_tail = (unsigned char*)(lcvy + DD_CAP * (size_t)L2); }
+  {
+    uint32_t* w = (uint32_t*)lds_tail;
+    if (nd.lds_flags & 1) { trzp = w; w += nzw; }
+    if (nd.lds_flags & 2) { trxp = w; w += nxw; ringx = (float*)w; w += 64 * L1; lckx = w; w += DD_CAP * L1; }
+    if (nd.lds_flags & 4) { tryp = w; w += nyw; ringy = (float*)w; w += 64 * L2; lcky = w; w += DD_CAP * L2; }
+  }
+  uint8_t* trz = nd.tr_z;
   nw_init_tr(L1, L2, trz);
   // sweep-order inputs of the three DPs, built once; the multiplier updates below keep them current
   dd_fill_scores(L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_x);
@@ -918,24 +933,46 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
   for (t = 0; t != prm.t_max; ++t) {
     for (uint32_t i = tid; i < L1; i += nt) nd.x[i] = DD_NONE;
     for (uint32_t k = tid; k < L2; k += nt) nd.y[k] = DD_NONE;
+    // packed traceback tables are filled by OR
+    if (trzp) for (uint32_t e = tid; e < nzw; e += nt) trzp[e] = 0;
+    if (trxp) for (uint32_t e = tid; e < nxw; e += nt) trxp[e] = 0;
+    if (tryp) for (uint32_t e = tid; e < nyw; e += nt) tryp[e] = 0;
     // the three subproblems (dafs.cpp:1091-1093) side by side, one wavefront each, DP then traceback
     __syncthreads();
     if (wave == 0) {
-      const float sc = (ringx && Wx <= DD_WREG) ? nuss_wave_fast(Wx, L1, nd.s_x, nd.wx, trx, nd.trk_x, ringx, lckx, lcvx, lane)
-                       : ringx ? nuss_wave_lds(L1, nd.s_x, nd.wx, trx, nd.trk_x, Px, Sbx, ccx, ringx, lckx, lcvx, lane)
-                             : nuss_wave(L1, nd.s_x, nd.wx, trx, nd.trk_x, Px, Sbx, ccx, lane);
+      bool slow = true;
+      float sc = 0.0f;
+      if (trxp && Wx <= DD_WREG) sc = nuss_wave_fast(Wx, L1, nd.s_x, trxp, ringx, lckx, lane, &slow);
+      if (slow && lane == 0 && prm.stamps) nd.info[4] += 1;  // iterations that took the slower form
+      if (slow) sc = nuss_wave(L1, nd.s_x, nd.wx, nd.trb_x, nd.trk_x, Px, Sbx, ccx, lane);
       DD_TICK(0);
-      if (lane == 0) { s_score[0] = sc; nuss_traceback_b(L1, trx, nd.trk_x, nd.x, (uint32_t*)Px); }
+      if (lane == 0) {
+        s_score[0] = sc;
+        if (slow) nuss_traceback_b(L1, nd.trb_x, nd.trk_x, nd.x, (uint32_t*)Px);
+        else nuss_traceback_fast(L1, trxp, lckx, nd.x, (uint32_t*)Px);
+      }
       DD_TICK(1);
     } else if (wave == 1) {
-      const float sc = (ringy && Wy <= DD_WREG) ? nuss_wave_fast(Wy, L2, nd.s_y, nd.wy, try_, nd.trk_y, ringy, lcky, lcvy, lane)
-                       : ringy ? nuss_wave_lds(L2, nd.s_y, nd.wy, try_, nd.trk_y, Py, Sby, ccy, ringy, lcky, lcvy, lane)
-                             : nuss_wave(L2, nd.s_y, nd.wy, try_, nd.trk_y, Py, Sby, ccy, lane);
-      if (lane == 0) { s_score[1] = sc; nuss_traceback_b(L2, try_, nd.trk_y, nd.y, (uint32_t*)Py); }
+      bool slow = true;
+      float sc = 0.0f;
+      if (tryp && Wy <= DD_WREG) sc = nuss_wave_fast(Wy, L2, nd.s_y, tryp, ringy, lcky, lane, &slow);
+      if (slow && lane == 0 && prm.stamps) nd.info[5] += 1;
+      if (slow) sc = nuss_wave(L2, nd.s_y, nd.wy, nd.trb_y, nd.trk_y, Py, Sby, ccy, lane);
+      if (lane == 0) {
+        s_score[1] = sc;
+        if (slow) nuss_traceback_b(L2, nd.trb_y, nd.trk_y, nd.y, (uint32_t*)Py);
+        else nuss_traceback_fast(L2, tryp, lcky, nd.y, (uint32_t*)Py);
+      }
     } else if (wave == 2) {
-      const float sc = Wz <= DD_WREG ? nw_wave_fast(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, trz, lane)
-                                     : nw_wave(L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, trz, Pz, Pbz, Qbz, lane);
-      if (lane == 0) { s_score[2] = sc; if (!nw_traceback(L1, L2, trz, nd.z)) s_bad = 1; }
+      float sc;
+      if (Wz <= DD_WREG) sc = trzp ? nw_wave_fast<true>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, (uint8_t*)trzp, lane)
+                                   : nw_wave_fast<false>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, trz, lane);
+      else sc = nw_wave(L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, trz, Pz, Pbz, Qbz, lane);
+      if (lane == 0) {
+        s_score[2] = sc;
+        const bool ok = (trzp && Wz <= DD_WREG) ? nw_traceback_packed(L1, L2, trzp, nd.z) : nw_traceback(L1, L2, trz, nd.z);
+        if (!ok) s_bad = 1;
+      }
     }
     DD_TICK(0);
     if (tid >= 192) {
