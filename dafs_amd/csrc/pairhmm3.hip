@@ -46,6 +46,8 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
   if (threadIdx.x < 56) s_match[threadIdx.x] = (&a.model.match[0][0])[threadIdx.x];
   if (threadIdx.x < 8) s_ins[threadIdx.x] = a.model.ins[threadIdx.x];
   __syncthreads();
+  pc_tables_init2(&s_tab, threadIdx.x, blockDim.x);
+  __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int t = lane % G;
@@ -119,14 +121,13 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
         for (int c = 0; c < W; ++c) {
           const int j = t * W + c;
           const float mt = s_match[c1 * 8 + cc[c]];
-          // ProbabilisticModel.h:152-155
-          float m = dM + tMM;
-          m = pc_log_add_t<LUT>(&s_tab, m, dX + tXM);
-          m = pc_log_add_t<LUT>(&s_tab, m, dY + tYM);
-          m += mt;
-          // :159-161 and :165-167
-          float x = insc1 + pc_log_add_t<LUT>(&s_tab, pM[c] + tMX, pX[c] + tXX);
-          float y = s_ins[cc[c]] + pc_log_add_t<LUT>(&s_tab, lM + tMY, lY + tYY);
+          // ProbabilisticModel.h:152-155 (M), :159-161 (X), :165-167 (Y): four LOG_ADDs, issued as two
+          // packed pairs -- M's first with X's, then M's second with Y's
+          const pc_f2 r1 = pc_log_add2<LUT>(&s_tab, pc_f2{dM + tMM, pM[c] + tMX}, pc_f2{dX + tXM, pX[c] + tXX});
+          const pc_f2 r2 = pc_log_add2<LUT>(&s_tab, pc_f2{r1.x, lM + tMY}, pc_f2{dY + tYM, lY + tYY});
+          float m = r2.x + mt;
+          float x = insc1 + r1.y;
+          float y = s_ins[cc[c]] + r2.y;
           if (c <= 1) {  // j <= 1 needs c <= 1: initial cells, :123-131 (cells with i<=1 && j<=1 are skipped by :150)
             if (i <= 1 && j <= 1) {
               m = (i == 1 && j == 1) ? fM11 : LZ;
@@ -144,6 +145,9 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
         lastM = pM[W - 1]; lastX = pX[W - 1]; lastY = pY[W - 1];
       }
     }
+#if defined(PAIR_EXP_STOP) && PAIR_EXP_STOP == 1  // tuning experiment: time of the forward sweep alone
+    if (endM != 12345.0f) continue;
+#endif
     const int tlast = (L2 >= 0 ? L2 : 0) / W;  // lane (within group) that owns column L2
     float totF = LZ;  // ComputeTotalProbability, :341-347 (B_k(L1,L2) = init_k)
     totF = pc_log_add_t<LUT>(&s_tab, totF, endM + i0);
@@ -179,21 +183,19 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
         for (int c = W - 1; c >= 0; --c) {
           const int j = t * W + c;
           const int c2 = cc[c + 1];  // class of s2[j] (iter2[j+1]); 'other' beyond the end
-          float bm = LZ, bx = LZ, by = LZ;
-          if (i == L1 && j == L2) { bm = i0; bx = i1; by = i2; }  // :213-214
-          // :233-237
+          // :233-237.  The cells start at LOG_ZERO (:213-214 sets the corner to the initial distribution), and
+          // LOG_ZERO (+) v == v for every v >= LOG_ZERO (the d >= 7.5 exit; v == LOG_ZERO gives LOG_ZERO), so
+          // the first accumulation is a plain assignment; at the corner the right-hand sides are LOG_ZERO
+          // (nothing lies beyond it) and the accumulation would return the initial values unchanged.
           const float pxy = dM + s_match[c1 * 8 + c2];
-          bm = pc_log_add_t<LUT>(&s_tab, bm, pxy + tMM);
-          bx = pc_log_add_t<LUT>(&s_tab, bx, pxy + tXM);
-          by = pc_log_add_t<LUT>(&s_tab, by, pxy + tYM);
-          // :238-243
+          float bm = pxy + tMM, bx = pxy + tXM, by = pxy + tYM;
+          if (i == L1 && j == L2) { bm = i0; bx = i1; by = i2; }
+          // :238-243 (M and X take the X-step term) and :244-249 (M and Y take the Y-step term), each a packed pair
           const float tx = pX[c] + insc1;
-          bm = pc_log_add_t<LUT>(&s_tab, bm, tx + tMX);
-          bx = pc_log_add_t<LUT>(&s_tab, bx, tx + tXX);
-          // :244-249
+          const pc_f2 q1 = pc_log_add2<LUT>(&s_tab, pc_f2{bm, bx}, pc_f2{tx + tMX, tx + tXX});
           const float ty = rgY + s_ins[c2];
-          bm = pc_log_add_t<LUT>(&s_tab, bm, ty + tMY);
-          by = pc_log_add_t<LUT>(&s_tab, by, ty + tYY);
+          const pc_f2 q2 = pc_log_add2<LUT>(&s_tab, pc_f2{q1.x, by}, pc_f2{ty + tMY, ty + tYY});
+          bm = q2.x; bx = q1.y; by = q2.y;
           dM = pM[c];
           pM[c] = bm; pX[c] = bx;
           rgY = by;
@@ -209,6 +211,9 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
         firstM = pM[0];
       }
     }
+#if defined(PAIR_EXP_STOP) && PAIR_EXP_STOP == 2  // tuning experiment: forward + backward
+    if (capM != 12345.0f) continue;
+#endif
     // ComputeTotalProbability, :349-364
     capM = __shfl(capM, g * G + (1 / W));
     capX = __shfl(capX, g * G);

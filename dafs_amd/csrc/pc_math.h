@@ -62,6 +62,11 @@ __device__ __forceinline__ float pc_exp(float xf) {
 // instead of a dozen selects.  pc_tables lives in LDS, filled by pc_tables_init.
 struct pc_tables {
   float4 lookup[12];   // LOOKUP cubic (k3,k2,k1,k0) valid on ((k-1)/2, k/2], k = min(ceil(2x), 10)
+  // the same cubics coefficient by coefficient (lk[0] = k3 ... lk[3] = k0): lanes that differ in k hit
+  // different banks, lanes that agree broadcast, so the reads are conflict-free.  The rows are 1040 bytes
+  // apart on purpose: closer, the compiler fuses the reads of one argument into ds_read2 pairs and then
+  // spends moves re-pairing them by coefficient for the packed multiply-adds.
+  float lk[4][260];
   double2 exp_hi[8];   // k4,k3 of the EXP quartics, index = clamp(exponent(|x|) + 2, 0, 6); [6] = zero
   double2 exp_mid[8];  // k2,k1
   double exp_lo[8];    // k0
@@ -91,6 +96,14 @@ __device__ __forceinline__ void pc_tables_init(pc_tables* t, int tid) {
   }
 }
 
+// second stage of the initialisation (after a barrier): the coefficient-wise copies
+__device__ __forceinline__ void pc_tables_init2(pc_tables* t, int tid, int nthreads) {
+  for (int e = tid; e < 12; e += nthreads) {
+    const float4 a = t->lookup[e];
+    t->lk[0][e] = a.x; t->lk[1][e] = a.y; t->lk[2][e] = a.z; t->lk[3][e] = a.w;
+  }
+}
+
 // LOOKUP (ScoreType.h:187-198).  The breakpoints 1.0, 2.5, 4.5 are multiples of 1/2 and every piece
 // is closed on the right, so the piece is a function of ceil(2x): no compare chain.
 __device__ __forceinline__ float pc_lookup_t(const pc_tables* t, float x) {
@@ -112,6 +125,33 @@ __device__ __forceinline__ float pc_log_add_t(const pc_tables* t, float x, float
   const float d = hi - lo;
   const float r = (LUT ? pc_lookup_t(t, d) : pc_lookup(d)) + lo;
   return d >= 7.5f ? hi : r;
+}
+
+// Two independent LOG_ADDs at once, (x.x (+) y.x, x.y (+) y.y), on the packed FP32 pipe: v_pk_mul_f32 /
+// v_pk_add_f32 do both lanes' multiply or add in one issue slot, and with contraction off they stay
+// separate roundings, i.e. the same operations as two calls of pc_log_add_t.
+typedef float pc_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pc_f2 pc_log_add2_t(const pc_tables* t, pc_f2 x, pc_f2 y) {
+  pc_f2 lo, hi;
+  lo.x = fminf(x.x, y.x); lo.y = fminf(x.y, y.y);
+  hi.x = fmaxf(x.x, y.x); hi.y = fmaxf(x.y, y.y);
+  const pc_f2 d = hi - lo;
+  const pc_f2 d2 = d * 2.0f;
+  const unsigned ka = (unsigned)fminf(ceilf(d2.x), 10.0f), kb = (unsigned)fminf(ceilf(d2.y), 10.0f);
+  const pc_f2 k3 = {t->lk[0][ka], t->lk[0][kb]}, k2 = {t->lk[1][ka], t->lk[1][kb]}, k1 = {t->lk[2][ka], t->lk[2][kb]}, k0 = {t->lk[3][ka], t->lk[3][kb]};
+  const pc_f2 r = (((k3 * d + k2) * d + k1) * d + k0) + lo;
+  pc_f2 o;
+  o.x = d.x >= 7.5f ? hi.x : r.x;
+  o.y = d.y >= 7.5f ? hi.y : r.y;
+  return o;
+}
+template <bool LUT>
+__device__ __forceinline__ pc_f2 pc_log_add2(const pc_tables* t, pc_f2 x, pc_f2 y) {
+  if (LUT) return pc_log_add2_t(t, x, y);
+  pc_f2 o;
+  o.x = pc_log_add_t<false>(t, x.x, y.x);
+  o.y = pc_log_add_t<false>(t, x.y, y.y);
+  return o;
 }
 
 // EXP (ScoreType.h:37-57) for x <= 0.  Piece boundaries are -1/2, -1, -2, -4, -8, -16, i.e. the
