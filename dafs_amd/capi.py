@@ -104,6 +104,10 @@ _make_brackets = _sig("dafs_hip_make_brackets", None, [C.c_uint32, C.c_void_p, C
 _dd_default_params = _sig("dafs_hip_dd_default_params", None, [C.POINTER(DDParams)])
 _solve_nodes = _sig("dafs_hip_solve_nodes", C.c_int,
                     [C.c_void_p, C.c_uint32, C.POINTER(NodeInput), C.POINTER(DDParams), C.POINTER(NodeOutput)])
+_nodes_open = _sig("dafs_hip_nodes_open", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(NodeInput), C.POINTER(DDParams), C.c_void_p])
+_nodes_advance = _sig("dafs_hip_nodes_advance", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(DDParams), C.c_uint32, C.c_void_p])
+_nodes_result = _sig("dafs_hip_nodes_result", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(NodeOutput)])
+_nodes_close = _sig("dafs_hip_nodes_close", C.c_int, [C.c_void_p])
 _consensus_structure = _sig("dafs_hip_consensus_structure", C.c_int,
                             [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                              C.POINTER(C.c_float), C.c_void_p])
@@ -296,6 +300,39 @@ class Context:
         check(_solve_nodes(self._h, n, ins, C.byref(prm), outs))
         return [dict(x=k[4], y=k[5], z=k[6], score=np.float32(outs[b].score), ncbp=outs[b].ncbp,
                      iterations=outs[b].iterations, violated=outs[b].violated) for b, k in enumerate(keep)]
+
+    # --- resident nodes (no level barrier) ---
+    def nodes_open(self, nodes, prm):
+        """nodes as in solve_nodes; returns their handles"""
+        n = len(nodes)
+        ins = (NodeInput * n)()
+        keep = []
+        for b, (s1, m1, s2, m2) in enumerate(nodes):
+            s1 = np.ascontiguousarray(s1, np.uint32); s2 = np.ascontiguousarray(s2, np.uint32)
+            m1 = np.ascontiguousarray(m1, np.uint8); m2 = np.ascontiguousarray(m2, np.uint8)
+            keep.append((s1, s2, m1, m2))
+            ins[b].n1, ins[b].n2, ins[b].len1, ins[b].len2 = m1.shape[0], m2.shape[0], m1.shape[1], m2.shape[1]
+            ins[b].seq1, ins[b].seq2, ins[b].mask1, ins[b].mask2 = s1.ctypes.data, s2.ctypes.data, m1.ctypes.data, m2.ctypes.data
+        handles = np.zeros(n, np.uint32)
+        check(_nodes_open(self._h, n, ins, C.byref(prm), handles.ctypes.data))
+        return [int(h) for h in handles], [(k[2].shape[1], k[3].shape[1]) for k in keep]
+
+    def nodes_advance(self, handles, prm, max_iterations):
+        """one launch: at most max_iterations more iterations for every listed node; returns the finished flags"""
+        h = np.ascontiguousarray(handles, np.uint32)
+        fin = np.zeros(len(h), np.uint8)
+        check(_nodes_advance(self._h, len(h), h.ctypes.data, C.byref(prm), max_iterations, fin.ctypes.data))
+        return fin.astype(bool)
+
+    def nodes_result(self, handle, len1, len2):
+        out = NodeOutput()
+        x = np.zeros(len1, np.uint32); y = np.zeros(len2, np.uint32); z = np.zeros(len1, np.uint32)
+        out.x, out.y, out.z = x.ctypes.data, y.ctypes.data, z.ctypes.data
+        check(_nodes_result(self._h, handle, C.byref(out)))
+        return dict(x=x, y=y, z=z, score=np.float32(out.score), ncbp=out.ncbp, iterations=out.iterations, violated=out.violated)
+
+    def nodes_close(self):
+        check(_nodes_close(self._h))
 
     def consensus_structure(self, seq, mask, th, want_p=False):
         seq = np.ascontiguousarray(seq, np.uint32); mask = np.ascontiguousarray(mask, np.uint8)

@@ -155,17 +155,23 @@ extern "C" void dafs_hip_dd_default_params(dafs_dd_params* p) {
   p->w = 4.0f; p->eta0 = 0.5f; p->th_a = 0.01f; p->th_s = 0.2f; p->t_max = 600; p->force_iters = 0;  // dafs.cpp:1612-1640
 }
 
-extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, const dafs_dd_params* prm,
-                                    dafs_node_output* out) {
-  if (!c || !in || !prm || !out || nnodes == 0) return DAFS_HIP_EINVAL;
-  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+namespace {
+
+dd_params device_params(const dafs_dd_params* prm) {
+  dd_params dp;
+  dp.w = prm->w; dp.eta0 = prm->eta0; dp.th_a = prm->th_a; dp.th_s = prm->th_s; dp.t_max = prm->t_max; dp.force_iters = prm->force_iters;
+  dp.stamps = getenv("DAFS_HIP_DD_STAMPS") ? 1 : 0;
+  dp.slice = 0;
+  return dp;
+}
+
+// Builds nnodes resident nodes (appended to c->dd_open): geometry upload, profile averages, sparse lists and
+// consensus constraints (DAFS::align_alignments up to the solve_by_dd call, dafs.cpp:896-960).
+int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, const dd_params& dp) {
   const mp_store& mps = c->mp[c->cur_mp];
   const bp_store& bps = c->bp[c->cur_bp];
   const uint32_t nseq = (uint32_t)c->len.size();
   if (!mps.valid || !bps.valid || mps.n_tasks != (uint64_t)nseq * (nseq - 1) / 2) return DAFS_HIP_EINVAL;
-  dd_params dp;
-  dp.w = prm->w; dp.eta0 = prm->eta0; dp.th_a = prm->th_a; dp.th_s = prm->th_s; dp.t_max = prm->t_max; dp.force_iters = prm->force_iters;
-  dp.stamps = getenv("DAFS_HIP_DD_STAMPS") ? 1 : 0;
 
   // ---- host geometry ----
   std::vector<geom> g1(nnodes), g2(nnodes);
@@ -178,17 +184,17 @@ extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs
     if ((rc = make_geom(c, ni.n2, ni.len2, ni.seq2, ni.mask2, g2[b]))) return rc;
   }
 
-  // ---- carve workspace A (two passes: size, then pointers) ----
+  // ---- carve each node's block (two passes: size, then pointers) ----
   std::vector<dd_node> nodes(nnodes);
-  size_t lds_max = 0;
-  std::vector<region> fills;
-  carver cv;
-  for (int pass = 0; pass < 2; ++pass) {
-    cv.used = 0;
-    fills.clear();
-    for (uint32_t b = 0; b < nnodes; ++b) {
-      const dafs_node_input& ni = in[b];
-      dd_node& nd = nodes[b];
+  std::vector<size_t> lds(nnodes, 0);
+  for (uint32_t b = 0; b < nnodes; ++b) {
+    const dafs_node_input& ni = in[b];
+    dd_node& nd = nodes[b];
+    carver cv;
+    std::vector<region> fills;
+    for (int pass = 0; pass < 2; ++pass) {
+      cv.used = 0;
+      fills.clear();
       memset(&nd, 0, sizeof nd);
       const uint32_t L1 = ni.len1, L2 = ni.len2;
       nd.n1 = ni.n1; nd.n2 = ni.n2; nd.L1 = L1; nd.L2 = L2;
@@ -214,11 +220,11 @@ extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs
       nd.trb_x = cv.take<uint8_t>(XX / 2 + L1 + 16); nd.trb_y = cv.take<uint8_t>(YY / 2 + L2 + 16);
       nd.s_x = cv.take<float>(((size_t)L1 + 63) * ((L1 + 63) / 64) * 64); nd.s_y = cv.take<float>(((size_t)L2 + 63) * ((L2 + 63) / 64) * 64);
       nd.pz_s = cv.take<float>(((size_t)L1 + 63) * ((L2 + 64) / 64) * 64); nd.qz_s = cv.take<float>(((size_t)L1 + 63) * ((L2 + 64) / 64) * 64);
-      nd.trk_x = nd.wx.tr; nd.trk_y = nd.wy.tr;  // the L*L uint32 tables double as bifurcation codes; the stack lives in wx.ck / wy.ck
-      {  // LDS plan: previous-row buffers + candidate counters, then traceback tables greedily (alignment, x, y)
+      nd.trk_x = nd.wx.tr; nd.trk_y = nd.wy.tr;  // the L*L uint32 tables double as bifurcation codes
+      {  // LDS plan: previous-row buffers + candidate counters of the HBM-table forms, then the on-chip forms
         size_t used = ((size_t)(2 * ((L1 + 63) / 64) + 2 * ((L2 + 63) / 64) + 3 * ((L2 + 64) / 64)) * 64 + L1 + L2) * 4;
         // granted in order of payoff: the fast x and y folding DPs (bits 1, 2: packed traceback nibbles, the 64
-        // rows in flight, DD_CAP candidates per column), then the packed alignment traceback (bit 0)
+        // rows in flight, DD_CAP split rows per column), then the packed alignment traceback (bit 0)
         const size_t need[3] = {(((size_t)T + 15) / 16) * 4, (((size_t)L1 * (L1 + 1) / 2 + 7) / 8 + (size_t)L1 * (64 + DD_CAP)) * 4,
                                 (((size_t)L2 * (L2 + 1) / 2 + 7) / 8 + (size_t)L2 * (64 + DD_CAP)) * 4};
         static const int order[3] = {1, 2, 0};
@@ -227,7 +233,7 @@ extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs
           const int k = order[o];
           if (used + need[k] <= kDdLdsBudget) { used += need[k]; nd.lds_flags |= 1u << k; }
         }
-        lds_max = std::max(lds_max, used);
+        lds[b] = used;
       }
       nd.env = cv.take<uint32_t>(2 * ((size_t)L1 + 1));
       nd.px_ptr = cv.take<uint32_t>((size_t)L1 + 2); nd.px_j = cv.take<uint32_t>(XX / 2 + 2);
@@ -237,20 +243,14 @@ extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs
       nd.cbp_cnt = cv.take<uint32_t>(XX / 2 + 2);
       nd.tx = cv.take<int32_t>(XX / 2 + 2); nd.ty = cv.take<int32_t>(YY / 2 + 2); nd.tz = cv.take<int32_t>(ZZ + 1);
       nd.x = cv.take<uint32_t>((size_t)L1 + 2); nd.y = cv.take<uint32_t>((size_t)L2 + 2); nd.z = cv.take<uint32_t>((size_t)L1 + 2);
-      nd.score = cv.take<float>(1); nd.info = cv.take<uint32_t>(16);
+      nd.score = cv.take<float>(1); nd.info = cv.take<uint32_t>(16); nd.fstate = cv.take<float>(4);
+      if (pass == 0) {
+        cv.base = c->dd_alloc(cv.used + 256);
+        if (!cv.base) return DAFS_HIP_ENOMEM;
+      }
     }
-    if (pass == 0) {
-      int rc = c->work.reserve(cv.used + 256);
-      if (rc) return rc;
-      cv.base = c->work.ptr;
-    }
-  }
-  // ---- upload geometry, fill, describe ----
-  for (const region& r : fills)
-    if (hip_check(hipMemsetAsync(c->work.ptr + r.off, r.value, r.bytes, c->stream))) return DAFS_HIP_ELAUNCH;
-  for (uint32_t b = 0; b < nnodes; ++b) {
-    const dafs_node_input& ni = in[b];
-    const dd_node& nd = nodes[b];
+    for (const region& r : fills)
+      if (hip_check(hipMemsetAsync(cv.base + r.off, r.value, r.bytes, c->stream))) return DAFS_HIP_ELAUNCH;
     auto up = [&](const void* dst, const void* src, size_t bytes) {
       return bytes == 0 || !hip_check(hipMemcpyAsync((void*)dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     };
@@ -266,56 +266,139 @@ extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs
   const bp_store_dev bpv = bps.view();
   if ((rc = dd_avg_launch(c->d_nodes.ptr, nnodes, mpv, bpv, c->stream))) return rc;
   if ((rc = dd_lists_launch(c->d_nodes.ptr, nnodes, dp, c->stream))) return rc;
-  // ---- consensus base-pair counts -> workspace B ----
+  // ---- consensus base-pair counts -> each node's second block ----
   std::vector<uint32_t> info(4 * (size_t)nnodes);
   for (uint32_t b = 0; b < nnodes; ++b)
     if (hip_check(hipMemcpyAsync(&info[4 * (size_t)b], nodes[b].info, 16, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
   if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
-  carver cb;
-  for (int pass = 0; pass < 2; ++pass) {
-    cb.used = 0;
-    for (uint32_t b = 0; b < nnodes; ++b) {
-      const uint32_t ncbp = info[4 * (size_t)b];
+  for (uint32_t b = 0; b < nnodes; ++b) {
+    const uint32_t ncbp = info[4 * (size_t)b];
+    carver cb;
+    for (int pass = 0; pass < 2; ++pass) {
+      cb.used = 0;
       nodes[b].ncbp_cap = ncbp;
       nodes[b].cbp = cb.take<uint32_t>((size_t)8 * ncbp + 8);
       nodes[b].sw = cb.take<float>((size_t)ncbp + 1);
-    }
-    if (pass == 0) {
-      if ((rc = c->work2.reserve(cb.used + 256))) return rc;
-      cb.base = c->work2.ptr;
+      if (pass == 0) {
+        cb.base = c->dd_alloc(cb.used + 256);
+        if (!cb.base) return DAFS_HIP_ENOMEM;
+      }
     }
   }
   if ((rc = c->d_nodes.upload(nodes.data(), nnodes, c->stream))) return rc;
   if ((rc = dd_cbp_fill_launch(c->d_nodes.ptr, nnodes, dp, c->stream))) return rc;
-  if ((rc = dd_solve_launch(c->d_nodes.ptr, nnodes, dp, lds_max, c->stream))) return rc;
-  // ---- results ----
-  std::vector<float> score(nnodes);
-  for (uint32_t b = 0; b < nnodes; ++b) {
-    const dd_node& nd = nodes[b];
-    auto down = [&](void* dst, const void* src, size_t bytes) {
-      return !dst || !hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-    };
-    bool ok = down(out[b].x, nd.x, (size_t)nd.L1 * 4) && down(out[b].y, nd.y, (size_t)nd.L2 * 4) && down(out[b].z, nd.z, (size_t)nd.L1 * 4) &&
-              down(&score[b], nd.score, 4) && down(&info[4 * (size_t)b], nd.info, 16);
-    if (!ok) return DAFS_HIP_ELAUNCH;
+  for (uint32_t b = 0; b < nnodes; ++b) c->dd_open.push_back({nodes[b], lds[b], false});
+  return DAFS_HIP_OK;
+}
+
+// One launch of the subgradient loop over the given resident nodes; finished[k] tells which of them are done.
+int nodes_advance(dafs_hip_ctx* c, uint32_t n, const uint32_t* handles, dd_params dp, uint32_t max_iterations, uint8_t* finished) {
+  std::vector<dd_node> nodes;
+  std::vector<uint32_t> who;
+  size_t lds_max = 0;
+  for (uint32_t k = 0; k < n; ++k) {
+    if (handles[k] >= c->dd_open.size()) return DAFS_HIP_EINVAL;
+    dafs_hip_ctx::dd_open_node& on = c->dd_open[handles[k]];
+    if (finished) finished[k] = on.finished ? 1 : 0;
+    if (on.finished) continue;
+    nodes.push_back(on.nd);
+    who.push_back(k);
+    lds_max = std::max(lds_max, on.lds);
   }
+  if (nodes.empty()) return DAFS_HIP_OK;
+  dp.slice = max_iterations;
+  int rc;
+  if ((rc = c->d_nodes.upload(nodes.data(), nodes.size(), c->stream))) return rc;
+  if ((rc = dd_solve_launch(c->d_nodes.ptr, (uint32_t)nodes.size(), dp, lds_max, c->stream))) return rc;
+  std::vector<uint32_t> info(8 * nodes.size());
+  for (size_t b = 0; b < nodes.size(); ++b)
+    if (hip_check(hipMemcpyAsync(&info[8 * b], nodes[b].info, 32, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
   if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
-  if (dp.stamps) {
-    for (uint32_t b = 0; b < nnodes; ++b) {
-      uint32_t tk[16];
-      if (hip_check(hipMemcpy(tk, nodes[b].info, sizeof tk, hipMemcpyDeviceToHost))) break;
-      fprintf(stderr, "dd node L1=%u L2=%u n=%u+%u ncbp=%u iters=%u slow-xy=%u+%u | us: x-dp %.0f x-traceback %.0f wait %.0f cbp %.0f update %.0f tail %.0f\n", nodes[b].L1,
-              nodes[b].L2, nodes[b].n1, nodes[b].n2, tk[0], tk[1], tk[4], tk[5], tk[8] / 100.0, tk[9] / 100.0, tk[10] / 100.0, tk[11] / 100.0, tk[12] / 100.0, tk[13] / 100.0);
-    }
-  }
-  for (uint32_t b = 0; b < nnodes; ++b) {
-    out[b].score = score[b];
-    out[b].ncbp = info[4 * (size_t)b];
-    out[b].iterations = info[4 * (size_t)b + 1];
-    out[b].violated = info[4 * (size_t)b + 2];
-    if (info[4 * (size_t)b + 3]) return DAFS_HIP_ELAUNCH;  // alignment traceback left the envelope
+  for (size_t b = 0; b < nodes.size(); ++b) {
+    const bool done = info[8 * b + 7] == 0;
+    c->dd_open[handles[who[b]]].finished = done;
+    if (finished) finished[who[b]] = done ? 1 : 0;
   }
   return DAFS_HIP_OK;
+}
+
+int nodes_result(dafs_hip_ctx* c, uint32_t handle, dafs_node_output* out, bool stamps) {
+  if (handle >= c->dd_open.size() || !c->dd_open[handle].finished) return DAFS_HIP_EINVAL;
+  const dd_node& nd = c->dd_open[handle].nd;
+  uint32_t info[16];
+  float score = 0.0f;
+  auto down = [&](void* dst, const void* src, size_t bytes) {
+    return !dst || !hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  };
+  bool ok = down(out->x, nd.x, (size_t)nd.L1 * 4) && down(out->y, nd.y, (size_t)nd.L2 * 4) && down(out->z, nd.z, (size_t)nd.L1 * 4) &&
+            down(&score, nd.score, 4) && down(info, nd.info, sizeof info);
+  if (!ok || hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
+  if (stamps)
+    fprintf(stderr, "dd node L1=%u L2=%u n=%u+%u ncbp=%u iters=%u slow-xy=%u+%u | us: x-dp %.0f x-traceback %.0f wait %.0f cbp %.0f update %.0f tail %.0f\n", nd.L1,
+            nd.L2, nd.n1, nd.n2, info[0], info[1], info[4], info[5], info[8] / 100.0, info[9] / 100.0, info[10] / 100.0, info[11] / 100.0, info[12] / 100.0,
+            info[13] / 100.0);
+  out->score = score;
+  out->ncbp = info[0];
+  out->iterations = info[1];
+  out->violated = info[2];
+  return info[3] ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;  // info[3]: the alignment traceback left the envelope
+}
+
+}  // namespace
+
+// ---- resident nodes: the progressive phase without level barriers --------------------------------
+// A node opened here stays on the device until dafs_hip_nodes_close.  dafs_hip_nodes_advance runs at
+// most max_iterations further subgradient iterations of every listed node in ONE launch and reports
+// which of them have finished; unfinished nodes simply take part in the next call, next to whatever
+// nodes became ready in the meantime.  A node's results do not depend on how its iterations were cut
+// into launches.
+extern "C" int dafs_hip_nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, const dafs_dd_params* prm, uint32_t* handles) {
+  if (!c || !in || !prm || !handles || nnodes == 0) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  const uint32_t first = (uint32_t)c->dd_open.size();
+  const int rc = nodes_open(c, nnodes, in, device_params(prm));
+  if (rc) { c->dd_open.resize(first); return rc; }
+  for (uint32_t b = 0; b < nnodes; ++b) handles[b] = first + b;
+  return DAFS_HIP_OK;
+}
+
+extern "C" int dafs_hip_nodes_advance(dafs_hip_ctx* c, uint32_t n, const uint32_t* handles, const dafs_dd_params* prm, uint32_t max_iterations,
+                                      uint8_t* finished) {
+  if (!c || !handles || !prm || n == 0) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  return nodes_advance(c, n, handles, device_params(prm), max_iterations, finished);
+}
+
+extern "C" int dafs_hip_nodes_result(dafs_hip_ctx* c, uint32_t handle, dafs_node_output* out) {
+  if (!c || !out) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  return nodes_result(c, handle, out, getenv("DAFS_HIP_DD_STAMPS") != nullptr);
+}
+
+extern "C" int dafs_hip_nodes_close(dafs_hip_ctx* c) {
+  if (!c) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
+  c->dd_reset();
+  return DAFS_HIP_OK;
+}
+
+// One batch of independent nodes, start to finish (the level-synchronous form; also what the refinement
+// steps use).  Not to be mixed with open resident nodes.
+extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, const dafs_dd_params* prm,
+                                    dafs_node_output* out) {
+  if (!c || !in || !prm || !out || nnodes == 0) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  if (!c->dd_open.empty()) return DAFS_HIP_EINVAL;
+  const dd_params dp = device_params(prm);
+  int rc = nodes_open(c, nnodes, in, dp);
+  std::vector<uint32_t> handles(nnodes);
+  for (uint32_t b = 0; b < nnodes; ++b) handles[b] = b;
+  if (!rc) rc = nodes_advance(c, nnodes, handles.data(), dp, 0, nullptr);
+  for (uint32_t b = 0; b < nnodes && !rc; ++b) rc = nodes_result(c, b, &out[b], dp.stamps != 0);
+  (void)hipStreamSynchronize(c->stream);
+  c->dd_reset();
+  return rc;
 }
 
 // Averaged base-pairing matrix of an alignment and its MEA structure: the final step of

@@ -117,11 +117,30 @@ struct dafs_hip_ctx {
   // progressive phase workspaces
   dafs::dev_buf<uint8_t> work, work2;
   dafs::dev_buf<dafs::dd_node> d_nodes;
+  // resident tree nodes (dafs_hip_nodes_open / _advance / _result / _close): device memory that lives until
+  // _close, in large chunks that are kept for the next phase
+  struct dd_chunk { uint8_t* ptr; size_t cap, used; };
+  std::vector<dd_chunk> dd_chunks;
+  struct dd_open_node { dafs::dd_node nd; size_t lds; bool finished; };
+  std::vector<dd_open_node> dd_open;
+  uint8_t* dd_alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    for (dd_chunk& ch : dd_chunks)
+      if (ch.cap - ch.used >= bytes) { uint8_t* p = ch.ptr + ch.used; ch.used += bytes; return p; }
+    dd_chunk ch;
+    ch.cap = bytes > ((size_t)256 << 20) ? bytes : ((size_t)256 << 20);
+    ch.used = bytes;
+    if (dafs::hip_check(hipMalloc((void**)&ch.ptr, ch.cap))) return nullptr;
+    dd_chunks.push_back(ch);
+    return ch.ptr;
+  }
+  void dd_reset() { for (dd_chunk& ch : dd_chunks) ch.used = 0; dd_open.clear(); }
+  void dd_release() { for (dd_chunk& ch : dd_chunks) (void)hipFree(ch.ptr); dd_chunks.clear(); dd_open.clear(); }
   uint32_t max_len() const { uint32_t m = 0; for (uint32_t l : len) m = l > m ? l : m; return m; }
 
   void free_all() {
     codes.release(); d_len.release(); d_seq_rp_off.release(); tasks.release(); scratch.release(); task_sim.release();
-    counters.release(); d_sim.release(); d_pair_x.release(); d_pair_y.release(); work.release(); work2.release(); d_nodes.release();
+    counters.release(); d_sim.release(); d_pair_x.release(); d_pair_y.release(); work.release(); work2.release(); d_nodes.release(); dd_release();
     d_cf_params.release(); cf_seqs.release(); cf_codes.release(); cf_iws.release(); cf_cons.release(); cf_fws.release(); cf_post.release(); cf_logz.release();
     for (int k = 0; k < 2; ++k) { mp[k].release(); bp[k].release(); }
   }

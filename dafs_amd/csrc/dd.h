@@ -43,7 +43,9 @@ struct dd_node {
   // results
   uint32_t *x, *y, *z;
   float* score;                   // [1]
-  uint32_t* info;                 // [16]: ncbp, iterations, violated, status; [8..13] optional phase ticks
+  uint32_t* info;                 // [16]: ncbp, iterations (next iteration while paused), violated, status, slow-x, slow-y,
+                                  //       started, paused; [8..13] optional phase ticks
+  float* fstate;                  // [4]: c, eta, previous dual value of a paused node
 };
 
 struct dd_params {
@@ -51,6 +53,8 @@ struct dd_params {
   uint32_t t_max;
   int force_iters;
   int stamps;  // accumulate per-phase timing into info[8..13] (tuning aid)
+  uint32_t slice;  // at most this many iterations per launch (0 = run to the end); a node that is cut short is
+                   // marked paused and continues from where it stopped at the next launch
 };
 
 int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, mp_store_dev mp, bp_store_dev bp, hipStream_t st);

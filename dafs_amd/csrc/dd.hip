@@ -804,7 +804,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes,
   nw_envelope(L1, L2, nd.p_z, prm.th_a, nd.env, nd.x, nd.z);  // x / z double as scratch here
   nw_init(L1, L2, nd.dp_z, nd.tr_z);
   __syncthreads();
-  if (tid == 0) { nd.info[0] = s_total; nd.info[1] = 0; nd.info[2] = 0; nd.info[3] = 0; nd.info[4] = 0; nd.info[5] = 0; }
+  if (tid == 0) { nd.info[0] = s_total; nd.info[1] = 0; nd.info[2] = 0; nd.info[3] = 0; nd.info[4] = 0; nd.info[5] = 0; nd.info[6] = 0; nd.info[7] = 0; }
 }
 
 __global__ __launch_bounds__(DD_THREADS) void k_node_cbp_fill(const dd_node* nodes, dd_params prm) {
@@ -889,7 +889,12 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
   __shared__ float s_score[3];
   float c = 0.0f, eta = prm.eta0, s_prev = 0.0f;  // meaningful in thread 0
   uint32_t t = 0, violated = 0;
-  if (tid == 0) { s_eta = eta; s_bad = 0; }
+  const bool resume = nd.info[6] != 0;  // a node paused by an earlier launch (prm.slice): pick up its loop state
+  const uint32_t t_first = resume ? nd.info[1] : 0;
+  if (tid == 0) {
+    if (resume) { c = nd.fstate[0]; eta = nd.fstate[1]; s_prev = nd.fstate[2]; }
+    s_eta = eta; s_bad = 0;
+  }
   // dynamic LDS: previous-row buffers and candidate counters of the three wave DPs, then whichever
   // traceback tables fit (nd.lds_flags, decided by the host): bit 0 alignment, bit 1 x, bit 2 y
   extern __shared__ unsigned char s_dd[];
@@ -918,11 +923,13 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
     if (nd.lds_flags & 4) { tryp = w; w += nyw; ringy = (float*)w; w += 64 * L2; lcky = w; w += DD_CAP * L2; }
   }
   uint8_t* trz = nd.tr_z;
-  nw_init_tr(L1, L2, trz);
-  // sweep-order inputs of the three DPs, built once; the multiplier updates below keep them current
-  dd_fill_scores(L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_x);
-  dd_fill_scores(L2, nd.p_y, nd.q_y, w_y, prm.th_s, nd.s_y);
-  dd_fill_nw(L1, L2, nd.p_z, nd.q_z, nd.pz_s, nd.qz_s);
+  if (!resume) {
+    nw_init_tr(L1, L2, trz);
+    // sweep-order inputs of the three DPs, built once; the multiplier updates below keep them current
+    dd_fill_scores(L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_x);
+    dd_fill_scores(L2, nd.p_y, nd.q_y, w_y, prm.th_s, nd.s_y);
+    dd_fill_nw(L1, L2, nd.p_z, nd.q_z, nd.pz_s, nd.qz_s);
+  }
   __syncthreads();
   const int wave = (int)(tid >> 6), lane = (int)(tid & 63);
 
@@ -930,7 +937,9 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
   unsigned long long tk[7] = {0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
 #define DD_TICK(k) if (prm.stamps && tid == 0) { const unsigned long long now = wall_clock64(); tk[k] += now - t_prev; t_prev = now; }
   if (prm.stamps && tid == 0) t_prev = wall_clock64();
-  for (t = 0; t != prm.t_max; ++t) {
+  uint32_t ran = 0;
+  bool paused = false;
+  for (t = t_first; t != prm.t_max; ++t) {
     for (uint32_t i = tid; i < L1; i += nt) nd.x[i] = DD_NONE;
     for (uint32_t k = tid; k < L2; k += nt) nd.y[k] = DD_NONE;
     // packed traceback tables are filled by OR
@@ -1128,14 +1137,21 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
     __syncthreads();
     DD_TICK(5);
     if (s_stop) break;
+    if (prm.slice && ++ran == prm.slice && t + 1 != prm.t_max) { paused = true; ++t; break; }  // to be continued
   }
   if (tid == 0) {
-    *nd.score = s_prev;
-    nd.info[1] = t;
-    nd.info[2] = violated;
-    nd.info[3] = s_bad ? 1u : 0u;
+    nd.info[6] = 1;
+    nd.info[7] = paused ? 1u : 0u;
+    nd.info[1] = t;  // iterations done; while paused, the next iteration
+    if (paused) {
+      nd.fstate[0] = c; nd.fstate[1] = eta; nd.fstate[2] = s_prev;
+    } else {
+      *nd.score = s_prev;
+      nd.info[2] = violated;
+      nd.info[3] = s_bad ? 1u : 0u;
+    }
     if (prm.stamps)
-      for (int k = 0; k < 6; ++k) nd.info[8 + k] = (uint32_t)tk[k];
+      for (int k = 0; k < 6; ++k) nd.info[8 + k] = (resume ? nd.info[8 + k] : 0u) + (uint32_t)tk[k];
   }
 }
 

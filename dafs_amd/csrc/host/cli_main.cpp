@@ -447,23 +447,65 @@ int run(const Options& o) {
     done[i] = true;
   }
   float s = 0.0f;
-  size_t remaining = tree.size() - N;
-  while (remaining) {
-    std::vector<uint> ready;
-    for (uint i = N; i < tree.size(); ++i)
-      if (!done[i] && done[tree[i].second.first] && done[tree[i].second.second]) ready.push_back(i);
-    std::vector<const ALN*> a1, a2;
-    for (uint i : ready) { a1.push_back(&aln[tree[i].second.first]); a2.push_back(&aln[tree[i].second.second]); }
-    std::vector<ALN> merged;
-    const std::vector<float> score = solve_batch(ctx, prm, a1, a2, merged, o.verbose);
-    for (size_t b = 0; b < ready.size(); ++b) {
-      aln[ready[b]].swap(merged[b]);
-      done[ready[b]] = true;
-      ALN().swap(aln[tree[ready[b]].second.first]);
-      ALN().swap(aln[tree[ready[b]].second.second]);
-      if (ready[b] == tree.size() - 1) s = score[b];
+  {
+    // The nodes stay resident on the device (dafs_hip_nodes_*): every round opens the nodes whose children
+    // are ready, advances all open nodes by at most kSlice iterations in one launch and merges the
+    // finished ones, so a node that needs the full iteration budget does not hold back its level.
+    const uint32_t kSlice = 64;
+    struct Open { uint node; uint32_t handle; NodeJob job; };
+    std::vector<Open> open;
+    size_t remaining = tree.size() - N;
+    std::vector<bool> opened(tree.size(), false);
+    while (remaining) {
+      std::vector<uint> ready;
+      for (uint i = N; i < tree.size(); ++i)
+        if (!done[i] && !opened[i] && done[tree[i].second.first] && done[tree[i].second.second]) ready.push_back(i);
+      if (!ready.empty()) {
+        const size_t first = open.size();
+        std::vector<dafs_node_input> in(ready.size());
+        for (size_t b = 0; b < ready.size(); ++b) {
+          open.push_back(Open{ready[b], 0, NodeJob()});
+          opened[ready[b]] = true;
+        }
+        for (size_t b = 0; b < ready.size(); ++b) {
+          const ALN &a1 = aln[tree[ready[b]].second.first], &a2 = aln[tree[ready[b]].second.second];
+          NodeJob& j = open[first + b].job;
+          flatten(a1, j.s1, j.m1);
+          flatten(a2, j.s2, j.m2);
+          in[b].n1 = (uint32_t)a1.size(); in[b].n2 = (uint32_t)a2.size();
+          in[b].len1 = (uint32_t)a1[0].second.size(); in[b].len2 = (uint32_t)a2[0].second.size();
+          in[b].seq1 = j.s1.data(); in[b].seq2 = j.s2.data(); in[b].mask1 = j.m1.data(); in[b].mask2 = j.m2.data();
+          j.x.resize(in[b].len1); j.y.resize(in[b].len2); j.z.resize(in[b].len1);
+        }
+        std::vector<uint32_t> handles(ready.size());
+        check(dafs_hip_nodes_open(ctx, (uint32_t)ready.size(), in.data(), &prm, handles.data()));
+        for (size_t b = 0; b < ready.size(); ++b) open[first + b].handle = handles[b];
+      }
+      std::vector<uint32_t> handles(open.size());
+      std::vector<uint8_t> fin(open.size());
+      for (size_t k = 0; k < open.size(); ++k) handles[k] = open[k].handle;
+      check(dafs_hip_nodes_advance(ctx, (uint32_t)open.size(), handles.data(), &prm, kSlice, fin.data()));
+      std::vector<Open> still;
+      for (size_t k = 0; k < open.size(); ++k) {
+        if (!fin[k]) { still.push_back(std::move(open[k])); continue; }
+        Open& o1 = open[k];
+        dafs_node_output r;
+        r.x = o1.job.x.data(); r.y = o1.job.y.data(); r.z = o1.job.z.data();
+        check(dafs_hip_nodes_result(ctx, o1.handle, &r));
+        const uint l = tree[o1.node].second.first, rr = tree[o1.node].second.second;
+        ALN merged;
+        project_alignment(merged, aln[l], aln[rr], o1.job.z);
+        aln[o1.node].swap(merged);
+        done[o1.node] = true;
+        ALN().swap(aln[l]);
+        ALN().swap(aln[rr]);
+        if (o.verbose >= 1) std::cerr << "Step: " << r.iterations << ", Violated: " << r.violated << std::endl;  // :1292
+        if (o1.node == tree.size() - 1) s = r.score;
+        --remaining;
+      }
+      open.swap(still);
     }
-    remaining -= ready.size();
+    check(dafs_hip_nodes_close(ctx));
   }
   ALN& root = aln[tree.size() - 1];
 

@@ -85,7 +85,7 @@ class Result:
 
 
 def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25, w_pct_s=0.25, th_a=0.01,
-        th_s=0.2, th_s1=None, align_model=capi.ALIGN_PROBCONS, force_iters=0, timers=None):
+        th_s=0.2, th_s1=None, align_model=capi.ALIGN_PROBCONS, force_iters=0, timers=None, level_sync=False, slice_iters=64):
     """The whole run.  bp: per-sequence (rowptr, col, val) base-pairing rows (--fold-aux); None
     computes them with the device fold model."""
     import time
@@ -110,22 +110,47 @@ def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25
     res.sim = sim
     res.tree = (score, left, right)
     res.tree_line = tree_string(score, left, right, names)
-    # progressive phase: solve every node whose children are ready, level by level
+    # progressive phase.  level_sync: solve every node whose children are ready, level by level (one blocking
+    # call per level).  Otherwise the nodes stay resident on the device and every round advances all open
+    # nodes by at most `slice_iters` iterations in one launch: a node that needs 600 iterations no longer
+    # holds back the parents of its level-mates.  Same results either way.
     lens = [len(s) for s in seqs]
     aln = {i: (np.array([i], np.uint32), np.ones((1, lens[i]), np.uint8)) for i in range(n)}
     pending = [i for i in range(n, 2 * n - 1)]
     prm = capi.dd_params(w=w, eta0=eta0, th_a=th_a, th_s=th_s, t_max=t_max, force_iters=force_iters)
     res.dd_log = {}
     res.levels = 0
-    while pending:
-        ready = [i for i in pending if left[i] in aln and right[i] in aln]
-        outs = ctx.solve_nodes([(aln[left[i]][0], aln[left[i]][1], aln[right[i]][0], aln[right[i]][1]) for i in ready], prm)
-        for i, o in zip(ready, outs):
-            aln[i] = project_alignment(aln[left[i]], aln[right[i]], o["z"])
-            res.dd_log[i] = (o["iterations"], o["violated"], o["ncbp"], o["score"])
-            del aln[left[i]], aln[right[i]]
-        pending = [i for i in pending if i not in ready]
-        res.levels += 1
+    if level_sync:
+        while pending:
+            ready = [i for i in pending if left[i] in aln and right[i] in aln]
+            outs = ctx.solve_nodes([(aln[left[i]][0], aln[left[i]][1], aln[right[i]][0], aln[right[i]][1]) for i in ready], prm)
+            for i, o in zip(ready, outs):
+                aln[i] = project_alignment(aln[left[i]], aln[right[i]], o["z"])
+                res.dd_log[i] = (o["iterations"], o["violated"], o["ncbp"], o["score"])
+                del aln[left[i]], aln[right[i]]
+            pending = [i for i in pending if i not in ready]
+            res.levels += 1
+    else:
+        open_nodes = {}  # node -> (handle, len1, len2)
+        while pending or open_nodes:
+            ready = [i for i in pending if left[i] in aln and right[i] in aln]
+            if ready:
+                hs, dims = ctx.nodes_open([(aln[left[i]][0], aln[left[i]][1], aln[right[i]][0], aln[right[i]][1]) for i in ready], prm)
+                for i, h, d in zip(ready, hs, dims):
+                    open_nodes[i] = (h, d[0], d[1])
+                pending = [i for i in pending if i not in ready]
+            ids = sorted(open_nodes)
+            fin = ctx.nodes_advance([open_nodes[i][0] for i in ids], prm, slice_iters)
+            for i, f in zip(ids, fin):
+                if not f:
+                    continue
+                h, l1, l2 = open_nodes.pop(i)
+                o = ctx.nodes_result(h, l1, l2)
+                aln[i] = project_alignment(aln[left[i]], aln[right[i]], o["z"])
+                res.dd_log[i] = (o["iterations"], o["violated"], o["ncbp"], o["score"])
+                del aln[left[i]], aln[right[i]]
+            res.levels += 1
+        ctx.nodes_close()
     root = 2 * n - 2
     sidx, mask = aln[root]
     t.append(time.perf_counter())

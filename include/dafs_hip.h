@@ -261,6 +261,17 @@ typedef struct {
 void dafs_hip_dd_default_params(dafs_dd_params* p);
 int dafs_hip_solve_nodes(dafs_hip_ctx* ctx, uint32_t nnodes, const dafs_node_input* in, const dafs_dd_params* prm,
                          dafs_node_output* out);
+
+/* The same solver with the nodes resident on the device, so that the progressive phase needs no level
+ * barrier: open the nodes whose children are ready, advance all open nodes by at most max_iterations
+ * subgradient iterations per call (one launch), collect the finished ones, open their parents, repeat.
+ * Replaces the recursion of DAFS::align (reference src/dafs.cpp:983-1004) as the driver of
+ * DAFS::align_alignments / solve_by_dd.  Results are those of dafs_hip_solve_nodes, bit for bit.        */
+int dafs_hip_nodes_open(dafs_hip_ctx* ctx, uint32_t nnodes, const dafs_node_input* in, const dafs_dd_params* prm, uint32_t* handles);
+int dafs_hip_nodes_advance(dafs_hip_ctx* ctx, uint32_t n, const uint32_t* handles, const dafs_dd_params* prm, uint32_t max_iterations,
+                           uint8_t* finished);
+int dafs_hip_nodes_result(dafs_hip_ctx* ctx, uint32_t handle, dafs_node_output* out);
+int dafs_hip_nodes_close(dafs_hip_ctx* ctx);
 /* Final common structure of an alignment (src/dafs.cpp:1857-1871 without the RNAalifold term):
  * averaged base-pairing matrix -> SparseNussinov::decode(p,ss,str) with threshold th. */
 int dafs_hip_consensus_structure(dafs_hip_ctx* ctx, uint32_t n, uint32_t len, const uint32_t* seq, const uint8_t* mask,

@@ -106,3 +106,19 @@ def test_iteration_cap_and_params(oracle):
     for kw in (dict(t_max=3), dict(w=2.0, eta0=0.25, th_s=0.1), dict(t_max=1, w_pct_a=0.0)):
         want, (it, vi), got = _run_both(oracle, names, seqs, bp, **kw)
         assert got.output == want, kw
+
+
+@pytest.mark.parametrize("slice_iters", [1, 7, 64])
+def test_resident_nodes_equal_level_batches(oracle, slice_iters):
+    """dafs_hip_nodes_open/_advance/_result: however the iterations of a node are cut into launches, and
+    whichever nodes share a launch, the run is the level-synchronous one (and the oracle's)."""
+    from dafs_amd import pipeline
+    from test_pct_gpu import random_bp
+    recs = synth.family_set(12, 60, seed=21)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    bp = random_bp(seqs, 21, density=0.04)
+    want, (it, vi), got = _run_both(oracle, names, seqs, bp, slice_iters=slice_iters)
+    ref = pipeline.run(names, seqs, bp=bp, level_sync=True)
+    assert got.output == want == ref.output
+    assert got.dd_log == ref.dd_log
+    assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
