@@ -264,7 +264,9 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
   if ((rc = c->d_nodes.upload(nodes.data(), nnodes, c->stream))) return rc;  // synchronises: host vectors stay valid until here
   const mp_store_dev mpv = mps.view(c->d_len.ptr, nseq);
   const bp_store_dev bpv = bps.view();
-  if ((rc = dd_avg_launch(c->d_nodes.ptr, nnodes, mpv, bpv, c->stream))) return rc;
+  uint32_t max_len = 0;
+  for (uint32_t b = 0; b < nnodes; ++b) max_len = std::max(max_len, std::max(in[b].len1, in[b].len2));
+  if ((rc = dd_avg_launch(c->d_nodes.ptr, nnodes, max_len, mpv, bpv, c->stream))) return rc;
   if ((rc = dd_lists_launch(c->d_nodes.ptr, nnodes, dp, c->stream))) return rc;
   // ---- consensus base-pair counts -> each node's second block ----
   std::vector<uint32_t> info(4 * (size_t)nnodes);
@@ -442,7 +444,7 @@ extern "C" int dafs_hip_consensus_structure(dafs_hip_ctx* c, uint32_t n, uint32_
   if ((rc = c->d_nodes.upload(&nd, 1, c->stream))) return rc;
   mp_store_dev none;
   memset(&none, 0, sizeof none);
-  if ((rc = dd_avg_launch(c->d_nodes.ptr, 1, none, bps.view(), c->stream))) return rc;
+  if ((rc = dd_avg_launch(c->d_nodes.ptr, 1, len, none, bps.view(), c->stream))) return rc;
   if ((rc = nussinov_launch(len, nd.p_x, nullptr, 0.0f, th, nd.wx, d_ss, nd.score, c->stream))) return rc;
   float s = 0;
   if (hip_check(hipMemcpyAsync(ss, d_ss, (size_t)len * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;

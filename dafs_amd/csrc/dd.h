@@ -57,7 +57,7 @@ struct dd_params {
                    // marked paused and continues from where it stopped at the next launch
 };
 
-int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, mp_store_dev mp, bp_store_dev bp, hipStream_t st);
+int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_store_dev mp, bp_store_dev bp, hipStream_t st);
 int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st);
 int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st);
 #define DD_CAP 4  // candidates per column kept in LDS by the fast folding DP

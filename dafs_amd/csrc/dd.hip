@@ -104,7 +104,12 @@ __device__ void nuss_pair_dp(uint32_t LA, const float* pA, const float* qA, floa
 // initialize (needleman_wunsch.cpp:198-253); fa/la = scratch of L1+1 uint32 each
 __device__ void nw_envelope(uint32_t L1, uint32_t L2, const float* __restrict__ p, float th, uint32_t* env,
                             uint32_t* fa, uint32_t* la) {
+  // first / last column of every row with p - th >= 0 in parallel, then the sequential smoothing passes
+  // (needleman_wunsch.cpp:196-243) by one thread on an LDS copy (2 x 1025 words) instead of global memory
+  __shared__ uint32_t s_env[2 * 1025], s_fl[2 * 1025];
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const bool in_lds = L1 <= 1024;
+  if (in_lds) { fa = s_fl; la = s_fl + 1025; }
   for (uint32_t i = tid + 1; i <= L1; i += nt) {
     uint32_t f = 0, l = 0;
     for (uint32_t k = 1; k <= L2; ++k)
@@ -116,28 +121,34 @@ __device__ void nw_envelope(uint32_t L1, uint32_t L2, const float* __restrict__ 
     la[i] = l;
   }
   __syncthreads();
+  uint32_t* ev = in_lds ? s_env : env;
   if (tid == 0) {
-    for (uint32_t i = 0; i <= L1; ++i) { env[2 * i] = 0; env[2 * i + 1] = 0; }
+    for (uint32_t i = 0; i <= L1; ++i) { ev[2 * i] = 0; ev[2 * i + 1] = 0; }
     for (uint32_t i = 1; i <= L1; ++i) {
-      if (fa[i]) {
-        if (fa[i] - 1 < env[2 * (i - 1)]) env[2 * (i - 1)] = fa[i] - 1;
-        env[2 * i] = fa[i];
+      const uint32_t f = fa[i], l = la[i];
+      if (f) {
+        if (f - 1 < ev[2 * (i - 1)]) ev[2 * (i - 1)] = f - 1;
+        ev[2 * i] = f;
       }
-      if (env[2 * i] == 0) {
-        env[2 * i] = env[2 * (i - 1)];
-        env[2 * i + 1] = env[2 * (i - 1) + 1];
+      if (ev[2 * i] == 0) {
+        ev[2 * i] = ev[2 * (i - 1)];
+        ev[2 * i + 1] = ev[2 * (i - 1) + 1];
         continue;
       }
-      if (la[i] - 1 > env[2 * (i - 1) + 1]) env[2 * (i - 1) + 1] = la[i] - 1;
-      env[2 * i + 1] = la[i];
+      if (l - 1 > ev[2 * (i - 1) + 1]) ev[2 * (i - 1) + 1] = l - 1;
+      ev[2 * i + 1] = l;
     }
-    env[2 * L1 + 1] = L2;
-    for (uint32_t i = L1, v = L2; i != 0; --i) { v = v < env[2 * i] ? v : env[2 * i]; env[2 * i] = v; }
-    for (uint32_t i = 0, v = 0; i != L1 + 1; ++i) { v = v > env[2 * i + 1] ? v : env[2 * i + 1]; env[2 * i + 1] = v; }
+    ev[2 * L1 + 1] = L2;
+    for (uint32_t i = L1, v = L2; i != 0; --i) { v = v < ev[2 * i] ? v : ev[2 * i]; ev[2 * i] = v; }
+    for (uint32_t i = 0, v = 0; i != L1 + 1; ++i) { v = v > ev[2 * i + 1] ? v : ev[2 * i + 1]; ev[2 * i + 1] = v; }
     for (uint32_t i = 1; i != L1 + 1; ++i)
-      if (env[2 * (i - 1) + 1] < env[2 * i]) env[2 * i] = env[2 * (i - 1) + 1];
+      if (ev[2 * (i - 1) + 1] < ev[2 * i]) ev[2 * i] = ev[2 * (i - 1) + 1];
   }
   __syncthreads();
+  if (in_lds) {
+    for (uint32_t i = tid; i < 2 * (L1 + 1); i += nt) env[i] = s_env[i];
+    __syncthreads();
+  }
 }
 
 // table initialisation (:262-274); cells inside the envelope are overwritten by every decode,
@@ -686,51 +697,111 @@ __global__ __launch_bounds__(DD_THREADS) void k_nw_single(uint32_t L1, uint32_t 
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// posterior averaging: one workgroup per (node, matrix); every thread owns whole rows so each
-// cell receives its addends in the reference's order (rows of aln1, then rows of aln2)
-// ------------------------------------------------------------------------------------------
+// Profile averages (average_matching_probability dafs.cpp:513-559, average_basepairing_probability
+// :561-607 without the alifold term).  Every cell of an averaged row receives at most one addend per
+// source (a row of one sequence, or a pair of rows), and the reference adds them source by source, so:
+// one wavefront per output row; the 64 lanes fetch the sparse rows of 64 sources at once (the pointer
+// chases of 64 lookups overlap) and park the addends as (column, value) in LDS in source order; then
+// every lane walks that list and applies the addends whose column it owns (column mod 64) to the row
+// accumulator in LDS -- each cell sees its addends in the reference's order, no atomics.
+#define AVG_STAGE 1024  // addends parked per round and wavefront
+struct avg_src { const uint32_t* col; const float* val; uint32_t n; const uint32_t* map; };
+
+template <class GetSrc>
+__device__ void avg_row(uint32_t nsrc, float scale_div, GetSrc get, float* row, uint2* stage, int lane) {
+  for (uint32_t base = 0; base < nsrc; base += 64) {
+    const uint32_t me = base + lane;
+    avg_src sr = {nullptr, nullptr, 0, nullptr};
+    if (me < nsrc) sr = get(me);
+    uint32_t first = 0;  // lanes < first have been applied
+    while (first < 64) {
+      // lanes first.. in order, as many as fit the staging area
+      uint32_t cnt = (uint32_t)lane >= first ? sr.n : 0u;
+      uint32_t incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+      }
+      const bool fits = incl <= AVG_STAGE;
+      const unsigned long long fm = __ballot(fits);
+      uint32_t last = first;
+      {  // fits is monotone over lanes >= first: first lane that does not fit
+        const unsigned long long nf = ~fm & ((~0ull) << first);
+        last = nf ? (uint32_t)(__ffsll((long long)nf) - 1) : 64u;
+      }
+      if ((uint32_t)lane >= first && (uint32_t)lane < last) {
+        const uint32_t pos = incl - cnt;
+        for (uint32_t e = 0; e < sr.n; ++e) stage[pos + e] = make_uint2(sr.map[sr.col[e]], __float_as_uint(sr.val[e] / scale_div));
+      }
+      uint32_t total = __shfl(incl, (int)(last ? last - 1 : 0));
+      if (last == first) total = 0;  // a single source larger than the stage cannot happen (rows hold <= 1024 entries)
+      wave_lds_fence();
+      for (uint32_t k = 0; k < total; ++k) {
+        const uint2 a = stage[k];
+        if ((a.x & 63u) == (uint32_t)lane) row[a.x] += __uint_as_float(a.y);
+      }
+      wave_lds_fence();
+      first = last == first ? 64u : last;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_node_avg(const dd_node* nodes, mp_store_dev mp, bp_store_dev bp) {
-  const dd_node nd = nodes[blockIdx.x / 3];
-  const uint32_t role = blockIdx.x % 3;
-  if (role < 2) {  // average_basepairing_probability, dafs.cpp:561-607 (no alifold term)
+  __shared__ float s_row[4][1024];
+  __shared__ uint2 s_stage[4][AVG_STAGE];
+  const dd_node nd = nodes[blockIdx.y];
+  const uint32_t role = blockIdx.z;
+  const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+  const uint32_t I = blockIdx.x * 4 + wave;
+  float* row = s_row[wave];
+  uint2* stage = s_stage[wave];
+  if (role < 2) {
     const uint32_t L = role ? nd.L2 : nd.L1, n = role ? nd.n2 : nd.n1;
+    if (I >= L) return;
     const uint32_t* seq = role ? nd.seq2 : nd.seq1;
     const uint32_t* rank = role ? nd.rank2 : nd.rank1;
     const uint32_t* idx = role ? nd.idx2 : nd.idx1;
     const uint32_t* idxoff = role ? nd.idxoff2 : nd.idxoff1;
-    float* P = role ? nd.p_y : nd.p_x;
-    for (uint32_t I = threadIdx.x; I < L; I += blockDim.x) {
-      float* row = P + (size_t)I * L;
-      for (uint32_t r = 0; r < n; ++r) {
-        const uint32_t ii = rank[(size_t)r * L + I];
-        if (ii == DD_NONE) continue;
+    float* P = (role ? nd.p_y : nd.p_x) + (size_t)I * L;
+    for (uint32_t J = lane; J < L; J += 64) row[J] = 0.0f;
+    wave_lds_fence();
+    avg_row(n, (float)n, [&](uint32_t r) {
+      avg_src sr = {nullptr, nullptr, 0, nullptr};
+      const uint32_t ii = rank[(size_t)r * L + I];
+      if (ii != DD_NONE) {
         const row_ref b = bp_row(bp, seq[r], ii);
-        const uint32_t* map = idx + idxoff[r];
-        for (uint32_t e = 0; e < b.n; ++e) row[map[b.col[e]]] += b.val[e] / n;
+        sr.col = b.col; sr.val = b.val; sr.n = b.n; sr.map = idx + idxoff[r];
       }
-      for (uint32_t J = I + 1; J < L; ++J)
-        if (row[J] <= DD_CUTOFF) row[J] = 0.0f;
+      return sr;
+    }, row, stage, lane);
+    for (uint32_t J = lane; J < L; J += 64) {
+      float v = row[J];
+      if (J > I && v <= DD_CUTOFF) v = 0.0f;
+      P[J] = v;
     }
-  } else {  // average_matching_probability, dafs.cpp:513-559
+  } else {
     const uint32_t L1 = nd.L1, L2 = nd.L2;
+    if (I >= L1) return;
     const uint32_t nn = nd.n1 * nd.n2;
-    for (uint32_t I = threadIdx.x; I < L1; I += blockDim.x) {
-      float* row = nd.p_z + (size_t)I * L2;
-      for (uint32_t r1 = 0; r1 < nd.n1; ++r1) {
-        const uint32_t ii = nd.rank1[(size_t)r1 * L1 + I];
-        if (ii == DD_NONE) continue;
-        const uint32_t s1 = nd.seq1[r1];
-        for (uint32_t r2 = 0; r2 < nd.n2; ++r2) {
-          const row_ref m = mp_row(mp, s1, nd.seq2[r2], ii);
-          const uint32_t* map = nd.idx2 + nd.idxoff2[r2];
-          for (uint32_t e = 0; e < m.n; ++e) row[map[m.col[e]]] += m.val[e] / nn;
-        }
-      }
-      for (uint32_t J = 0; J < L2; ++J) {
-        if (row[J] <= DD_CUTOFF) row[J] = 0.0f;
-        if (row[J] > 1.0f) row[J] = 1.0f;
-      }
+    float* P = nd.p_z + (size_t)I * L2;
+    for (uint32_t J = lane; J < L2; J += 64) row[J] = 0.0f;
+    wave_lds_fence();
+    for (uint32_t r1 = 0; r1 < nd.n1; ++r1) {
+      const uint32_t ii = nd.rank1[(size_t)r1 * L1 + I];
+      if (ii == DD_NONE) continue;
+      const uint32_t s1 = nd.seq1[r1];
+      avg_row(nd.n2, (float)nn, [&](uint32_t r2) {
+        const row_ref m = mp_row(mp, s1, nd.seq2[r2], ii);
+        avg_src sr = {m.col, m.val, m.n, nd.idx2 + nd.idxoff2[r2]};
+        return sr;
+      }, row, stage, lane);
+    }
+    for (uint32_t J = lane; J < L2; J += 64) {
+      float v = row[J];
+      if (v <= DD_CUTOFF) v = 0.0f;
+      if (v > 1.0f) v = 1.0f;
+      P[J] = v;
     }
   }
 }
@@ -745,6 +816,40 @@ __device__ __forceinline__ bool cbp_ok(const dd_node& nd, const dd_params& prm, 
   return (p - prm.th_s > 0.0f) && (prm.w * (p - prm.th_s) + (q - prm.th_a) > 0.0f);
 }
 
+// In-place inclusive prefix sum of a[0..n) by the whole workgroup: every thread sums a contiguous
+// chunk, the DD_THREADS chunk sums are scanned in LDS, every thread rewrites its chunk.  (A single
+// thread walking a global array pays a memory round trip per element.)
+__device__ void block_scan_inclusive(uint32_t* a, uint32_t n) {
+  __shared__ uint32_t s_part[DD_THREADS];
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t chunk = (n + nt - 1) / nt;
+  const uint32_t b = tid * chunk < n ? tid * chunk : n, e = b + chunk < n ? b + chunk : n;
+  uint32_t sum = 0;
+  for (uint32_t i = b; i < e; ++i) sum += a[i];
+  s_part[tid] = sum;
+  __syncthreads();
+  if (tid < 64) {  // one wavefront scans the partials, eight per lane
+    const uint32_t per = (nt + 63) / 64;
+    uint32_t loc = 0;
+    for (uint32_t k = 0; k < per; ++k) { const uint32_t id = tid * per + k; if (id < nt) loc += s_part[id]; }
+    uint32_t incl = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o);
+      if ((int)tid >= o) incl += up;
+    }
+    uint32_t run = incl - loc;
+    for (uint32_t k = 0; k < per; ++k) {
+      const uint32_t id = tid * per + k;
+      if (id < nt) { const uint32_t v = s_part[id]; s_part[id] = run; run += v; }
+    }
+  }
+  __syncthreads();
+  uint32_t run = s_part[tid];
+  for (uint32_t i = b; i < e; ++i) { run += a[i]; a[i] = run; }
+  __syncthreads();
+}
+
 __device__ void row_lists(uint32_t R, uint32_t Cn, const float* P, bool upper, uint32_t* ptr, uint32_t* lst, int32_t* map) {
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   for (uint32_t i = tid; i < R; i += nt) {
@@ -752,12 +857,9 @@ __device__ void row_lists(uint32_t R, uint32_t Cn, const float* P, bool upper, u
     for (uint32_t j = upper ? i + 1 : 0; j < Cn; ++j) c += P[(size_t)i * Cn + j] > DD_CUTOFF ? 1 : 0;
     ptr[i + 1] = c;
   }
+  if (tid == 0) ptr[0] = 0;
   __syncthreads();
-  if (tid == 0) {
-    ptr[0] = 0;
-    for (uint32_t i = 0; i < R; ++i) ptr[i + 1] += ptr[i];
-  }
-  __syncthreads();
+  block_scan_inclusive(ptr + 1, R);
   for (uint32_t i = tid; i < R; i += nt) {
     uint32_t pos = ptr[i];
     for (uint32_t j = upper ? i + 1 : 0; j < Cn; ++j)
@@ -782,8 +884,8 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes,
   if (tid == 0) s_total = 0;
   __syncthreads();
   uint32_t mine = 0;
-  for (uint32_t i = 0; i < L1; ++i)
-    for (uint32_t e = nd.px_ptr[i] + tid; e < nd.px_ptr[i + 1]; e += nt) {
+  for (uint32_t i = tid; i < L1; i += nt)  // a thread per row of p_x: the rows hold a handful of entries each
+    for (uint32_t e = nd.px_ptr[i]; e < nd.px_ptr[i + 1]; ++e) {
       const uint32_t j = nd.px_j[e];
       const float px = nd.p_x[(size_t)i * L1 + j];
       uint32_t c = 0;
@@ -812,17 +914,14 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_cbp_fill(const dd_node* nod
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const uint32_t L1 = nd.L1, L2 = nd.L2;
   const uint32_t npx = nd.px_ptr[L1];
-  // exclusive prefix of the per-entry counts (entries are already in (i,j) order)
-  if (tid == 0) {
-    uint32_t run = 0;
-    for (uint32_t e = 0; e < npx; ++e) { const uint32_t c = nd.cbp_cnt[e]; nd.cbp_cnt[e] = run; run += c; }
-  }
-  __syncthreads();
-  for (uint32_t i = 0; i < L1; ++i)
-    for (uint32_t e = nd.px_ptr[i] + tid; e < nd.px_ptr[i + 1]; e += nt) {
+  // prefix of the per-entry counts (entries are already in (i,j) order); entry e starts at incl[e] - count[e],
+  // i.e. at incl[e-1]
+  block_scan_inclusive(nd.cbp_cnt, npx);
+  for (uint32_t i = tid; i < L1; i += nt)
+    for (uint32_t e = nd.px_ptr[i]; e < nd.px_ptr[i + 1]; ++e) {
       const uint32_t j = nd.px_j[e];
       const float px = nd.p_x[(size_t)i * L1 + j];
-      uint32_t u = nd.cbp_cnt[e];
+      uint32_t u = e ? nd.cbp_cnt[e - 1] : 0u;
       const uint32_t u0 = u;
       for (uint32_t a = nd.pz_ptr[i]; a < nd.pz_ptr[i + 1]; ++a) {
         const uint32_t k = nd.pz_k[a];
@@ -851,12 +950,9 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_cbp_fill(const dd_node* nod
     for (uint32_t k = 0; k < L2; ++k) c += nd.cz_flag[(size_t)i * L2 + k];
     nd.cz_ptr[i + 1] = c;
   }
+  if (tid == 0) nd.cz_ptr[0] = 0;
   __syncthreads();
-  if (tid == 0) {
-    nd.cz_ptr[0] = 0;
-    for (uint32_t i = 0; i < L1; ++i) nd.cz_ptr[i + 1] += nd.cz_ptr[i];
-  }
-  __syncthreads();
+  block_scan_inclusive(nd.cz_ptr + 1, L1);
   for (uint32_t i = tid; i < L1; i += nt) {
     uint32_t pos = nd.cz_ptr[i];
     for (uint32_t k = 0; k < L2; ++k)
@@ -1158,9 +1254,10 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, mp_store_dev mp, bp_store_dev bp, hipStream_t st) {
+int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_store_dev mp, bp_store_dev bp, hipStream_t st) {
   if (!nnodes) return DAFS_HIP_OK;
-  hipLaunchKernelGGL(k_node_avg, dim3(nnodes * 3), dim3(256), 0, st, d_nodes, mp, bp);
+  if (max_len > 1024) return DAFS_HIP_ETOOLONG;
+  hipLaunchKernelGGL(k_node_avg, dim3((max_len + 3) / 4, nnodes, 3), dim3(256), 0, st, d_nodes, mp, bp);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st) {
