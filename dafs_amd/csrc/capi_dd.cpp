@@ -178,7 +178,7 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
   for (uint32_t b = 0; b < nnodes; ++b) {
     const dafs_node_input& ni = in[b];
     if (!ni.n1 || !ni.n2 || !ni.len1 || !ni.len2 || !ni.seq1 || !ni.seq2 || !ni.mask1 || !ni.mask2) return DAFS_HIP_EINVAL;
-    if (ni.len1 > 1024 || ni.len2 > 1023) return DAFS_HIP_ETOOLONG;  // wave DPs: 64 lanes x 16 columns
+    if (ni.len1 > DD_LMAX || ni.len2 > DD_LMAX - 1) return DAFS_HIP_ETOOLONG;  // wave DPs: 64 lanes x 64 columns
     int rc;
     if ((rc = make_geom(c, ni.n1, ni.len1, ni.seq1, ni.mask1, g1[b]))) return rc;
     if ((rc = make_geom(c, ni.n2, ni.len2, ni.seq2, ni.mask2, g2[b]))) return rc;

@@ -235,7 +235,8 @@ __device__ __forceinline__ size_t tri_index(uint32_t L, uint32_t i, uint32_t j) 
 // reference's span loop, so the per-column candidate lists are built in the same order.
 // trb: one byte per upper-triangle cell (0..3, 4 = bifurcation with k in trk); dp/ck/cv in HBM
 // (dp read back for the bifurcation terms through L2); cc, P in LDS.
-#define DD_WMAX 16  // columns per lane in the wave DPs: sequences up to 64*16 = 1024 columns
+#define DD_WMAX 16  // columns per lane whose next-step inputs are prefetched through registers; wider lanes (alignments
+                   // beyond 1024 columns, up to DD_LMAX) fetch the rest at the end of the step
 
 // S: pair scores w*(p-th)-q (or p-th), precomputed by the whole workgroup (dd_fill_scores).  Row i of S
 // is fetched one step ahead into registers (16 independent loads) and parked in LDS (Sb) for the next step,
@@ -305,6 +306,7 @@ __device__ float nuss_wave(uint32_t L, const float* __restrict__ S, const nuss_w
 #pragma unroll
     for (int c = 0; c < DD_WMAX; ++c)
       if ((uint32_t)c < W) Sb[c * 64 + lane] = nxt[c];
+    for (uint32_t c = DD_WMAX; c < W; ++c) Sb[c * 64 + lane] = nv ? S[((size_t)(s + 1) * W + c) * 64 + lane] : 0.0f;
   }
   return __shfl(score, (int)((L - 1) / W));
 }
@@ -659,6 +661,10 @@ __device__ float nw_wave(uint32_t L1, uint32_t L2, const float* __restrict__ ps,
 #pragma unroll
     for (int c = 0; c < DD_WMAX; ++c)
       if ((uint32_t)c < W) { Pb[c * 64 + lane] = np[c]; Qb[c * 64 + lane] = nq[c]; }
+    for (uint32_t c = DD_WMAX; c < W; ++c) {
+      Pb[c * 64 + lane] = nv ? ps[((size_t)(s + 1) * W + c) * 64 + lane] : 0.0f;
+      Qb[c * 64 + lane] = nv ? qs[((size_t)(s + 1) * W + c) * 64 + lane] : 0.0f;
+    }
   }
   return __shfl(score, (int)(L2 / W));
 }
@@ -735,26 +741,31 @@ __device__ void avg_row(uint32_t nsrc, float scale_div, GetSrc get, float* row, 
         for (uint32_t e = 0; e < sr.n; ++e) stage[pos + e] = make_uint2(sr.map[sr.col[e]], __float_as_uint(sr.val[e] / scale_div));
       }
       uint32_t total = __shfl(incl, (int)(last ? last - 1 : 0));
-      if (last == first) total = 0;  // a single source larger than the stage cannot happen (rows hold <= 1024 entries)
+      if (last == first) {  // one source alone exceeds the stage (a row with more than AVG_STAGE entries): its lane applies it
+        total = 0;
+        if ((uint32_t)lane == first)
+          for (uint32_t e = 0; e < sr.n; ++e) row[sr.map[sr.col[e]]] += sr.val[e] / scale_div;
+        last = first + 1;
+      }
       wave_lds_fence();
       for (uint32_t k = 0; k < total; ++k) {
         const uint2 a = stage[k];
         if ((a.x & 63u) == (uint32_t)lane) row[a.x] += __uint_as_float(a.y);
       }
       wave_lds_fence();
-      first = last == first ? 64u : last;
+      first = last;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void k_node_avg(const dd_node* nodes, mp_store_dev mp, bp_store_dev bp) {
-  __shared__ float s_row[4][1024];
+__global__ __launch_bounds__(256) void k_node_avg(const dd_node* nodes, mp_store_dev mp, bp_store_dev bp, uint32_t row_cap) {
+  extern __shared__ float s_rows[];  // 4 x row_cap: one accumulator row per wavefront
   __shared__ uint2 s_stage[4][AVG_STAGE];
   const dd_node nd = nodes[blockIdx.y];
   const uint32_t role = blockIdx.z;
   const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
   const uint32_t I = blockIdx.x * 4 + wave;
-  float* row = s_row[wave];
+  float* row = s_rows + (size_t)wave * row_cap;
   uint2* stage = s_stage[wave];
   if (role < 2) {
     const uint32_t L = role ? nd.L2 : nd.L1, n = role ? nd.n2 : nd.n1;
@@ -1256,8 +1267,15 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
 // ------------------------------------------------------------------------------------------
 int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_store_dev mp, bp_store_dev bp, hipStream_t st) {
   if (!nnodes) return DAFS_HIP_OK;
-  if (max_len > 1024) return DAFS_HIP_ETOOLONG;
-  hipLaunchKernelGGL(k_node_avg, dim3((max_len + 3) / 4, nnodes, 3), dim3(256), 0, st, d_nodes, mp, bp);
+  if (max_len > DD_LMAX) return DAFS_HIP_ETOOLONG;
+  const uint32_t row_cap = (max_len + 63) & ~63u;
+  const size_t lds = (size_t)4 * row_cap * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hip_check(hipFuncSetAttribute((const void*)k_node_avg, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * DD_LMAX * 4))) return DAFS_HIP_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_node_avg, dim3((max_len + 3) / 4, nnodes, 3), dim3(256), lds, st, d_nodes, mp, bp, row_cap);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st) {

@@ -122,3 +122,15 @@ def test_resident_nodes_equal_level_batches(oracle, slice_iters):
     assert got.output == want == ref.output
     assert got.dd_log == ref.dd_log
     assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
+
+
+def test_alignments_beyond_1024_columns(oracle):
+    """Child alignments longer than 64 lanes x 16 columns take the wide forms of the node kernels
+    (inputs fetched at the end of the step, accumulator rows sized at launch)."""
+    from test_pct_gpu import random_bp
+    recs = synth.random_set(3, 1100, seed=31)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    assert max(len(s) for s in seqs) > 1024
+    want, (it, vi), got = _run_both(oracle, names, seqs, random_bp(seqs, 31, density=0.003), t_max=4)
+    assert got.output == want
+    assert len(got.rows[0]) > 1024
