@@ -153,7 +153,28 @@ extern "C" int dafs_hip_consistency(dafs_hip_ctx* c, float w_pct_a, float w_pct_
       a.rp_off = out.rp_off.ptr; a.rowptr_pool = out.rowptr_pool.ptr; a.col = out.col.ptr; a.val = out.val.ptr;
       a.pool_top = c->counters.ptr; a.pool_cap = cap; a.pair_off = out.pair_off.ptr; a.pair_nnz = out.pair_nnz.ptr;
       a.status = (int*)(c->counters.ptr + 2);
-      if ((rc = pct_match_launch(a, max_len, c->stream))) return rc;
+      // dense row tiles, in batches of at most kTileFloats; the tile memory is the pair kernels' scratch
+      const uint64_t kTileFloats = 1ull << 31;  // 8 GiB
+      for (uint64_t p0 = 0; p0 < all;) {
+        std::vector<uint64_t> toff;
+        uint64_t cells = 0, p1 = p0;
+        while (p1 < all) {
+          const uint64_t need = (uint64_t)c->len[raw.pair_x[p1]] * c->len[raw.pair_y[p1]];
+          if (p1 > p0 && cells + need > kTileFloats) break;
+          toff.push_back(cells);
+          cells += need;
+          ++p1;
+        }
+        if ((rc = c->scratch.reserve(cells + 64))) return rc;
+        const size_t cnt = (size_t)(p1 - p0);
+        if ((rc = c->work.reserve(cnt * 8 + 256))) return rc;
+        if ((rc = c->work2.reserve(cnt * 4 + 256))) return rc;
+        if (hip_check(hipMemcpyAsync(c->work.ptr, toff.data(), cnt * 8, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
+        if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;  // toff dies at the end of the scope
+        a.tile = c->scratch.ptr; a.tile_off = (const uint64_t*)c->work.ptr; a.sum_w = (float*)c->work2.ptr;
+        if ((rc = pct_match_launch(a, max_len, (uint32_t)p0, (uint32_t)cnt, c->stream))) return rc;
+        p0 = p1;
+      }
       unsigned long long h[4];
       if (hip_check(hipMemcpyAsync(h, c->counters.ptr, sizeof h, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
       if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;

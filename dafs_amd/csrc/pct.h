@@ -23,7 +23,11 @@ struct pct_match_args {
   uint64_t* pair_off;
   uint32_t* pair_nnz;
   int* status;
-  uint32_t max_len, tile_cells;  // filled by the launcher
+  // dense row tiles of the pairs of one launch: tile + tile_off[k] is the L1 x L2 tile of the launch's k-th pair
+  float* tile;
+  const uint64_t* tile_off;
+  float* sum_w;           // per pair of the launch: sum of the weights w_z (written by the row kernel)
+  uint32_t max_len;       // filled by the launcher
 };
 
 struct pct_bp_args {
@@ -43,7 +47,7 @@ struct pct_bp_args {
   uint32_t max_len, tile_cells;
 };
 
-int pct_match_launch(pct_match_args a, uint32_t max_len, hipStream_t st);
+int pct_match_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint32_t count, hipStream_t st);
 int pct_bp_launch(pct_bp_args a, uint32_t max_len, hipStream_t st);
 
 }  // namespace dafs

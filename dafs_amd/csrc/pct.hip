@@ -23,130 +23,291 @@ namespace dafs {
 
 #define PCT_CUTOFF 0.01f  // reference CUTOFF is the double 0.01; for a float v, v > 0.01 <=> v > 0.01f
 
-__global__ __launch_bounds__(256) void k_pct_match(pct_match_args a) {
-  extern __shared__ float s_mem[];
+// ---------------------------------------------------------------------------------------------
+// relax_matching_probability in two kernels.
+//
+// k_pct_rows: one wavefront per output row i of a pair (x,y).  The addends of the row are
+//   mp[x][z][i][k] * mp[z][y][k][j] * w_z, added to cell j in the order z, k, j (dafs.cpp:290-318).
+//   For a chunk of 32 sequences z the wave first fetches all rows mp[x][z][i] (one lane per z), then
+//   the row pointers of every mp[z][y][k] they reference (one lane per (z,k) "item"), then the entries
+//   of those rows (one lane per addend), so the pointer chases of a whole chunk overlap; the addends
+//   are applied item by item -- the columns of one item are distinct, so its lanes update the row
+//   accumulator (LDS) together, and consecutive items follow each other in program order.  The
+//   finished row goes to a dense tile in HBM.
+// k_pct_emit: one workgroup per pair turns the tile into the thresholded CSR and transposed CSR
+//   (rows by wavefronts with ballot compaction, columns by threads), bump-allocated like k_pairhmm3's.
+// ---------------------------------------------------------------------------------------------
+#define PCT_G 16            // lanes per output row
+#define PCT_ROWS_PER_WG 16  // 256 threads / PCT_G
+
+template <int Q>
+__device__ __forceinline__ uint32_t row_bcast(uint32_t v) {  // lane Q of every 16-lane row, to the whole row
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + Q, 0xF, 0xF, false);
+}
+template <int Q>
+__device__ __forceinline__ float row_bcastf(float v) { return __uint_as_float(row_bcast<Q>(__float_as_uint(v))); }
+
+struct pct_item {  // one (z, k) of a row, held by one lane of the row's group
+  uint32_t ptr_lo, ptr_hi;  // first entry of mp[z][y][k] in the pool
+  uint32_t n;               // its entries; an identity row (z == y) has n == 1 and ptr == ~0
+  uint32_t j;               // the column of an identity row
+  float pik, w;
+};
+
+// Items Q..15 of a round: phase A fetches the first 16 entries of every item's b-row (all loads in flight
+// together), phase B applies the items in order.  Entries of one item have distinct columns, so the lanes
+// of a group update the row accumulator together; the groups of a wavefront are different rows.
+template <int Q>
+struct pct_round {
+  static __device__ __forceinline__ void fetch(const pct_match_args& a, const pct_item& it, int t, uint32_t (&jc)[16], float (&pv)[16]) {
+    const uint32_t n = row_bcast<Q>(it.n), lo = row_bcast<Q>(it.ptr_lo), hi = row_bcast<Q>(it.ptr_hi), jid = row_bcast<Q>(it.j);
+    const bool ident = (lo & hi) == 0xFFFFFFFFu;
+    jc[Q] = jid; pv[Q] = 1.0f;
+    if ((uint32_t)t < n && !ident) {
+      const uint64_t e = (((uint64_t)hi << 32) | lo) + (uint32_t)t;
+      jc[Q] = a.in.col[e]; pv[Q] = a.in.val[e];
+    }
+    pct_round<Q + 1>::fetch(a, it, t, jc, pv);
+  }
+  static __device__ __forceinline__ void apply(const pct_match_args& a, const pct_item& it, int t, const uint32_t (&jc)[16], const float (&pv)[16], float* acc) {
+    const uint32_t n = row_bcast<Q>(it.n);
+    const float pik = row_bcastf<Q>(it.pik), w = row_bcastf<Q>(it.w);
+    if ((uint32_t)t < n) acc[jc[Q]] += pik * pv[Q] * w;  // dafs.cpp:300 / :308 / :316
+    if (__any(n > 16)) {  // a b-row longer than the group: the rest of it, before the next item
+      const uint32_t lo = row_bcast<Q>(it.ptr_lo), hi = row_bcast<Q>(it.ptr_hi);
+      const uint64_t base = ((uint64_t)hi << 32) | lo;
+      uint32_t nmax = n;
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, o));
+      for (uint32_t e0 = 16; e0 < nmax; e0 += 16) {
+        wave_lds_fence();
+        if (e0 + (uint32_t)t < n) { const uint64_t e = base + e0 + (uint32_t)t; acc[a.in.col[e]] += pik * a.in.val[e] * w; }
+      }
+    }
+    wave_lds_fence();
+    pct_round<Q + 1>::apply(a, it, t, jc, pv, acc);
+  }
+};
+template <>
+struct pct_round<16> {
+  static __device__ __forceinline__ void fetch(const pct_match_args&, const pct_item&, int, uint32_t (&)[16], float (&)[16]) {}
+  static __device__ __forceinline__ void apply(const pct_match_args&, const pct_item&, int, const uint32_t (&)[16], const float (&)[16], float*) {}
+};
+
+__global__ __launch_bounds__(256) void k_pct_rows(pct_match_args a, uint32_t pair0, uint32_t row_cap) {
+  extern __shared__ unsigned char s_raw[];
   const uint32_t N = a.in.nseq;
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
-  float* wz = s_mem;                                      // N
-  uint32_t* rowptr = (uint32_t*)(wz + N);                 // max_len + 2
-  uint32_t* colptr = rowptr + a.max_len + 2;              // max_len + 2
-  uint32_t* colcur = colptr + a.max_len + 2;              // max_len + 2
-  float* acc = (float*)(colcur + a.max_len + 2);          // tile_cells
-  __shared__ float s_sum_w;
+  const int t = (int)(tid & 15), gw = (int)(tid >> 4);
+  // workgroup tables, per z: row-pointer base and entry base of mp[x][z] and of mp[z][y], and w_z
+  uint64_t* a_rp = (uint64_t*)s_raw;
+  uint64_t* a_ent = a_rp + N;
+  uint64_t* b_rp = a_ent + N;
+  uint64_t* b_ent = b_rp + N;
+  float* wz = (float*)(b_ent + N);
+  // per group (= per output row): a-row bookkeeping of the current chunk of 16 sequences, then the accumulator row
+  unsigned char* gbase = (unsigned char*)(wz + ((N + 1) & ~1u)) + (size_t)gw * ((size_t)row_cap * 4 + 16 * 8 + 20 * 4 + 16 * 4);
+  uint64_t* zaent = (uint64_t*)gbase;
+  uint32_t* zoff = (uint32_t*)(zaent + 16);
+  uint32_t* zid = zoff + 20;
+  float* acc = (float*)(zid + 16);
+
+  const uint32_t p = pair0 + blockIdx.x;
+  const uint32_t x = a.pair_x[p], y = a.pair_y[p];
+  const uint32_t L1 = a.in.len[x], L2 = a.in.len[y];
+  const uint32_t row0 = blockIdx.y * PCT_ROWS_PER_WG;
+  if (row0 >= L1) return;
+  // dafs.cpp:280-288 and the bases of the two sparse matrices every z contributes
+  for (uint32_t z = tid; z < N; z += nt) {
+    float w = a.sim[(size_t)z * N + x] * a.sim[(size_t)z * N + y];
+    if (a.w_pct < 0.0) w *= 1.0 / N;
+    else if (z == x || z == y) w *= (1.0 - a.w_pct) / 2;
+    else w *= a.w_pct / (N - 2);
+    wz[z] = w;
+    // mp[x][z] (for z == y this is mp[x][y] itself; for z == x unused) and mp[z][y] (for z == x: mp[x][y]; z == y unused)
+    const uint32_t za = (z == x) ? y : z;
+    {
+      const uint32_t lo = x < za ? x : za, hi = x < za ? za : x;
+      const uint32_t tk = a.in.task_of_pair[pair_id(lo, hi, N)];
+      const bool fwd = x < za;
+      a_rp[z] = a.in.rp_off[tk] + (fwd ? 0 : a.in.len[lo] + 1);
+      a_ent[z] = a.in.pair_off[tk] + (fwd ? 0 : a.in.pair_nnz[tk]);
+    }
+    const uint32_t zb = (z == y) ? x : z;
+    {
+      const uint32_t lo = zb < y ? zb : y, hi = zb < y ? y : zb;
+      const uint32_t tk = a.in.task_of_pair[pair_id(lo, hi, N)];
+      const bool fwd = zb < y;
+      b_rp[z] = a.in.rp_off[tk] + (fwd ? 0 : a.in.len[lo] + 1);
+      b_ent[z] = a.in.pair_off[tk] + (fwd ? 0 : a.in.pair_nnz[tk]);
+    }
+  }
+  __syncthreads();
+  if (blockIdx.y == 0 && tid == 0) {
+    float sw = 0.0f;
+    for (uint32_t z = 0; z < N; ++z) sw += wz[z];
+    a.sum_w[blockIdx.x] = sw;
+  }
+  float* tile = a.tile + a.tile_off[blockIdx.x];
+
+  const uint32_t i = row0 + (uint32_t)gw;
+  const bool rowact = i < L1;
+  for (uint32_t j = (uint32_t)t; j < L2; j += PCT_G) acc[j] = 0.0f;
+  for (uint32_t zc = 0; zc < N; zc += PCT_G) {
+    // ---- a-rows of the chunk, one lane per z
+    uint32_t na = 0;
+    {
+      const uint32_t z = zc + (uint32_t)t;
+      uint32_t id = z;
+      uint64_t ent = 0;
+      if (rowact && z < N) {
+        if (z == x) { na = 1; id |= 0x80000000u; }  // mp[x][x][i] = {(i, 1)}
+        else {
+          const uint32_t beg = a.in.rowptr_pool[a_rp[z] + i], end = a.in.rowptr_pool[a_rp[z] + i + 1];
+          na = end - beg;
+          ent = a_ent[z] + beg;
+          if (z == y) id |= 0x40000000u;             // mp[y][y][k] = {(k, 1)}
+        }
+      }
+      zaent[t] = ent;
+      zid[t] = id;
+    }
+    uint32_t incl = na;
+#pragma unroll
+    for (int o = 1; o < PCT_G; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o, PCT_G);
+      if (t >= o) incl += up;
+    }
+    zoff[t + 1] = incl;
+    if (t == 0) zoff[0] = 0;
+    const uint32_t T1 = row_bcast<15>(incl);  // items of this row in this chunk
+    uint32_t T1max = T1;
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) T1max = max(T1max, (uint32_t)__shfl_xor((int)T1max, o));
+    T1max = __builtin_amdgcn_readfirstlane(T1max);
+    wave_lds_fence();
+    // ---- rounds of 16 items per row
+    for (uint32_t w0 = 0; w0 < T1max; w0 += PCT_G) {
+      const uint32_t tl = w0 + (uint32_t)t;
+      pct_item it;
+      it.ptr_lo = 0; it.ptr_hi = 0; it.n = 0; it.j = 0; it.pik = 0.0f; it.w = 0.0f;
+      uint32_t k = 0, id = 0;
+      const bool have = tl < T1;
+      if (have) {
+        uint32_t zz = 0;
+#pragma unroll
+        for (int q = 1; q < PCT_G; ++q) zz += (tl >= zoff[q]) ? 1u : 0u;
+        id = zid[zz];
+        k = i;
+        it.pik = 1.0f;
+        if (!(id & 0x80000000u)) { const uint64_t e = zaent[zz] + (tl - zoff[zz]); k = a.in.col[e]; it.pik = a.in.val[e]; }
+      }
+      if (have) {
+        const uint32_t z = id & 0x3FFFFFFFu;
+        it.w = wz[z];
+        it.j = k;
+        if (id & 0x40000000u) { it.n = 1; it.ptr_lo = 0xFFFFFFFFu; it.ptr_hi = 0xFFFFFFFFu; }
+        else {
+          const uint32_t bb = a.in.rowptr_pool[b_rp[z] + k], be = a.in.rowptr_pool[b_rp[z] + k + 1];
+          const uint64_t ptr = b_ent[z] + bb;
+          it.n = be - bb; it.ptr_lo = (uint32_t)ptr; it.ptr_hi = (uint32_t)(ptr >> 32);
+        }
+      }
+      uint32_t jc[16];
+      float pv[16];
+      pct_round<0>::fetch(a, it, t, jc, pv);
+      pct_round<0>::apply(a, it, t, jc, pv, acc);
+    }
+    wave_lds_fence();
+  }
+  if (rowact)
+    for (uint32_t j = (uint32_t)t; j < L2; j += PCT_G) tile[(size_t)i * L2 + j] = acc[j];
+}
+
+__global__ __launch_bounds__(256) void k_pct_emit(pct_match_args a, uint32_t pair0) {
+  extern __shared__ uint32_t s_ptrs[];  // rowptr[max_len + 2], colptr[max_len + 2]
+  __shared__ uint32_t s_part[256];
   __shared__ unsigned long long s_off;
   __shared__ int s_ok;
-
-  for (uint32_t p = blockIdx.x; p < a.npairs; p += gridDim.x) {
-    const uint32_t x = a.pair_x[p], y = a.pair_y[p];
-    const uint32_t L1 = a.in.len[x], L2 = a.in.len[y];
-    // dafs.cpp:280-288
-    for (uint32_t z = tid; z < N; z += nt) {
-      float w = a.sim[(size_t)z * N + x] * a.sim[(size_t)z * N + y];
-      if (a.w_pct < 0.0) w *= 1.0 / N;
-      else if (z == x || z == y) w *= (1.0 - a.w_pct) / 2;
-      else w *= a.w_pct / (N - 2);
-      wz[z] = w;
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const int wave = (int)(tid >> 6), lane = (int)(tid & 63);
+  uint32_t* rowptr = s_ptrs;
+  uint32_t* colptr = s_ptrs + a.max_len + 2;
+  const uint32_t p = pair0 + blockIdx.x;
+  const uint32_t x = a.pair_x[p], y = a.pair_y[p];
+  const uint32_t L1 = a.in.len[x], L2 = a.in.len[y];
+  const float* tile = a.tile + a.tile_off[blockIdx.x];
+  const float sum_w = a.sum_w[blockIdx.x];
+  // counts: rows by wavefronts, columns by threads
+  for (uint32_t i = (uint32_t)wave; i < L1; i += 4) {
+    uint32_t c = 0;
+    for (uint32_t j0 = 0; j0 < L2; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      const bool keep = j < L2 && tile[(size_t)i * L2 + j] / sum_w > PCT_CUTOFF;
+      c += (uint32_t)__popcll(__ballot(keep));
     }
-    for (uint32_t j = tid; j <= L2; j += nt) { colptr[j] = 0; colcur[j] = 0; }
+    if (lane == 0) rowptr[i + 1] = c;
+  }
+  for (uint32_t j = tid; j < L2; j += nt) {
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < L1; ++i) c += (tile[(size_t)i * L2 + j] / sum_w > PCT_CUTOFF) ? 1 : 0;
+    colptr[j + 1] = c;
+  }
+  if (tid == 0) { rowptr[0] = 0; colptr[0] = 0; }
+  __syncthreads();
+  // inclusive prefix sums in LDS (two arrays, chunked over the threads)
+  for (int which = 0; which < 2; ++which) {
+    uint32_t* arr = (which ? colptr : rowptr) + 1;
+    const uint32_t n = which ? L2 : L1;
+    const uint32_t chunk = (n + nt - 1) / nt;
+    const uint32_t b = tid * chunk < n ? tid * chunk : n, e = b + chunk < n ? b + chunk : n;
+    uint32_t sum = 0;
+    for (uint32_t k = b; k < e; ++k) sum += arr[k];
+    s_part[tid] = sum;
     __syncthreads();
     if (tid == 0) {
-      float s = 0.0f;
-      for (uint32_t z = 0; z < N; ++z) s += wz[z];
-      s_sum_w = s;
+      uint32_t run = 0;
+      for (uint32_t k = 0; k < nt; ++k) { const uint32_t v = s_part[k]; s_part[k] = run; run += v; }
     }
     __syncthreads();
-    const float sum_w = s_sum_w;
-    const uint32_t TI = min(L1, a.tile_cells / L2);
-    const uint32_t ntiles = (L1 + TI - 1) / TI;
-    const int npass = ntiles == 1 ? 1 : 2;
-    unsigned long long off = 0;
-    uint32_t nnz = 0;
-    bool ok = true;
-
-    for (int pass = 0; pass < npass; ++pass) {
-      const bool last = pass == npass - 1;
-      for (uint32_t tile = 0; tile < ntiles; ++tile) {
-        const uint32_t i0 = tile * TI;
-        const uint32_t rows = min(TI, L1 - i0);
-        for (uint32_t c = tid; c < rows * L2; c += nt) acc[c] = 0.0f;
-        __syncthreads();
-        for (uint32_t r = tid; r < rows; r += nt) {
-          const uint32_t i = i0 + r;
-          float* arow = acc + (size_t)r * L2;
-          for (uint32_t z = 0; z < N; ++z) {
-            const float w = wz[z];
-            if (z == x) {  // mp[x][x][k] = {(k,1)}: only k == i reaches row i
-              const row_ref b = mp_row(a.in, x, y, i);
-              for (uint32_t e = 0; e < b.n; ++e) arow[b.col[e]] += 1.0f * b.val[e] * w;
-            } else if (z == y) {  // mp[y][y][k] = {(k,1)}
-              const row_ref ar = mp_row(a.in, x, y, i);
-              for (uint32_t e = 0; e < ar.n; ++e) arow[ar.col[e]] += ar.val[e] * 1.0f * w;
-            } else {
-              const row_ref ar = mp_row(a.in, x, z, i);  // (k, p_ik), k ascending
-              for (uint32_t ea = 0; ea < ar.n; ++ea) {
-                const float p_ik = ar.val[ea];
-                const row_ref b = mp_row(a.in, z, y, ar.col[ea]);  // (j, p_jk)
-                for (uint32_t eb = 0; eb < b.n; ++eb) arow[b.col[eb]] += p_ik * b.val[eb] * w;
-              }
-            }
-          }
-        }
-        __syncthreads();
-        if (pass == 0) {  // count rows and columns of this tile
-          for (uint32_t r = tid; r < rows; r += nt) {
-            uint32_t c = 0;
-            for (uint32_t j = 0; j < L2; ++j) c += (acc[(size_t)r * L2 + j] / sum_w > PCT_CUTOFF) ? 1 : 0;
-            rowptr[i0 + r + 1] = c;
-          }
-          for (uint32_t j = tid; j < L2; j += nt) {
-            uint32_t c = 0;
-            for (uint32_t r = 0; r < rows; ++r) c += (acc[(size_t)r * L2 + j] / sum_w > PCT_CUTOFF) ? 1 : 0;
-            colptr[j + 1] += c;
-          }
-          __syncthreads();
-        }
-        if (pass == 0 && tile == ntiles - 1) {  // all counts known: prefix sums + pool reservation
-          if (tid == 0) {
-            rowptr[0] = 0;
-            for (uint32_t i = 0; i < L1; ++i) rowptr[i + 1] += rowptr[i];
-            colptr[0] = 0;
-            for (uint32_t j = 0; j < L2; ++j) colptr[j + 1] += colptr[j];
-            const uint32_t n = rowptr[L1];
-            const unsigned long long o = atomicAdd(a.pool_top, 2ull * n);
-            s_off = o;
-            s_ok = (o + 2ull * n <= a.pool_cap) ? 1 : 0;
-            if (!s_ok) atomicExch(a.status, DAFS_HIP_EOVERFLOW);
-            a.pair_off[p] = o;
-            a.pair_nnz[p] = n;
-          }
-          __syncthreads();
-          off = s_off;
-          ok = s_ok != 0;
-          nnz = rowptr[L1];
-          const uint64_t rp = a.rp_off[p];
-          for (uint32_t i = tid; i <= L1; i += nt) a.rowptr_pool[rp + i] = rowptr[i];
-          for (uint32_t j = tid; j <= L2; j += nt) a.rowptr_pool[rp + L1 + 1 + j] = colptr[j];
-        }
-        if (last && ok) {  // emit this tile: rows by row-threads, columns by column-threads
-          for (uint32_t r = tid; r < rows; r += nt) {
-            unsigned long long pos = off + rowptr[i0 + r];
-            for (uint32_t j = 0; j < L2; ++j) {
-              const float v = acc[(size_t)r * L2 + j] / sum_w;
-              if (v > PCT_CUTOFF) { a.col[pos] = j; a.val[pos] = v; ++pos; }
-            }
-          }
-          for (uint32_t j = tid; j < L2; j += nt) {
-            unsigned long long pos = off + nnz + colptr[j] + colcur[j];
-            uint32_t c = 0;
-            for (uint32_t r = 0; r < rows; ++r) {
-              const float v = acc[(size_t)r * L2 + j] / sum_w;
-              if (v > PCT_CUTOFF) { a.col[pos] = i0 + r; a.val[pos] = v; ++pos; ++c; }
-            }
-            colcur[j] += c;
-          }
-        }
-        __syncthreads();
+    uint32_t run = s_part[tid];
+    for (uint32_t k = b; k < e; ++k) { run += arr[k]; arr[k] = run; }
+    __syncthreads();
+  }
+  const uint32_t nnz = rowptr[L1];
+  if (tid == 0) {
+    const unsigned long long o = atomicAdd(a.pool_top, 2ull * nnz);
+    s_off = o;
+    s_ok = (o + 2ull * nnz <= a.pool_cap) ? 1 : 0;
+    if (!s_ok) atomicExch(a.status, DAFS_HIP_EOVERFLOW);
+    a.pair_off[p] = o;
+    a.pair_nnz[p] = nnz;
+  }
+  __syncthreads();
+  const unsigned long long off = s_off;
+  const uint64_t rp = a.rp_off[p];
+  for (uint32_t i = tid; i <= L1; i += nt) a.rowptr_pool[rp + i] = rowptr[i];
+  for (uint32_t j = tid; j <= L2; j += nt) a.rowptr_pool[rp + L1 + 1 + j] = colptr[j];
+  if (!s_ok) return;
+  for (uint32_t i = (uint32_t)wave; i < L1; i += 4) {
+    unsigned long long pos = off + rowptr[i];
+    for (uint32_t j0 = 0; j0 < L2; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      const float v = j < L2 ? tile[(size_t)i * L2 + j] / sum_w : 0.0f;
+      const bool keep = j < L2 && v > PCT_CUTOFF;
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const unsigned long long q = pos + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        a.col[q] = j; a.val[q] = v;
       }
+      pos += (uint32_t)__popcll(m);
+    }
+  }
+  for (uint32_t j = tid; j < L2; j += nt) {
+    unsigned long long pos = off + nnz + colptr[j];
+    for (uint32_t i = 0; i < L1; ++i) {
+      const float v = tile[(size_t)i * L2 + j] / sum_w;
+      if (v > PCT_CUTOFF) { a.col[pos] = i; a.val[pos] = v; ++pos; }
     }
   }
 }
@@ -266,18 +427,25 @@ __global__ __launch_bounds__(256) void k_pct_bp(pct_bp_args a) {
 
 static const size_t kPctLdsBytes = 150 * 1024;  // leave room for the static LDS and alignment
 
-int pct_match_launch(pct_match_args a, uint32_t max_len, hipStream_t st) {
-  const size_t fixed = ((size_t)a.in.nseq + 3 * ((size_t)max_len + 2)) * 4;
-  if (fixed + (size_t)max_len * 4 > kPctLdsBytes) return DAFS_HIP_ETOOLONG;
+size_t pct_rows_lds_bytes(uint32_t nseq, uint32_t row_cap) {
+  return (size_t)nseq * 32 + (((size_t)nseq + 1) & ~(size_t)1) * 4 + (size_t)PCT_ROWS_PER_WG * ((size_t)row_cap * 4 + 16 * 8 + 20 * 4 + 16 * 4) + 64;
+}
+
+// pairs [pair0, pair0 + count) whose tiles (a.tile, a.tile_off, a.sum_w) have been laid out by the caller
+int pct_match_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint32_t count, hipStream_t st) {
+  if (!count) return DAFS_HIP_OK;
+  const uint32_t row_cap = (max_len + 15) & ~15u;
+  const size_t lds = pct_rows_lds_bytes(a.in.nseq, row_cap);
+  if (lds > kPctLdsBytes) return DAFS_HIP_ETOOLONG;
   a.max_len = max_len;
-  a.tile_cells = (uint32_t)((kPctLdsBytes - fixed) / 4);
   static bool attr = false;
   if (!attr) {
-    if (hip_check(hipFuncSetAttribute((const void*)k_pct_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPctLdsBytes))) return DAFS_HIP_ELAUNCH;
+    if (hip_check(hipFuncSetAttribute((const void*)k_pct_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPctLdsBytes))) return DAFS_HIP_ELAUNCH;
     attr = true;
   }
-  const uint32_t grid = a.npairs < 4096 ? a.npairs : 4096;
-  hipLaunchKernelGGL(k_pct_match, dim3(grid), dim3(256), kPctLdsBytes, st, a);
+  hipLaunchKernelGGL(k_pct_rows, dim3(count, (max_len + PCT_ROWS_PER_WG - 1) / PCT_ROWS_PER_WG), dim3(256), lds, st, a, pair0, row_cap);
+  if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
+  hipLaunchKernelGGL(k_pct_emit, dim3(count), dim3(256), (size_t)2 * (max_len + 2) * 4, st, a, pair0);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 
