@@ -111,6 +111,17 @@ extern "C" int dafs_hip_consistency(dafs_hip_ctx* c, float w_pct_a, float w_pct_
       a.out_rowptr = out.rowptr.ptr; a.out_col = out.col.ptr; a.out_val = out.val.ptr;
       a.pool_top = c->counters.ptr; a.pool_cap = cap; a.out_off = out.bp_off.ptr; a.out_nnz = out.nnz.ptr;
       a.status = (int*)(c->counters.ptr + 2);
+      {  // dense tiles, one per sequence
+        std::vector<uint64_t> toff(n);
+        uint64_t cells = 0;
+        for (uint32_t x = 0; x < n; ++x) { toff[x] = cells; cells += (uint64_t)c->len[x] * c->len[x]; }
+        if ((rc = c->scratch.reserve(cells + 64))) return rc;
+        if ((rc = c->work.reserve((size_t)n * 8 + 256))) return rc;
+        if ((rc = c->work2.reserve((size_t)n * 4 + 256))) return rc;
+        if (hip_check(hipMemcpyAsync(c->work.ptr, toff.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
+        if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
+        a.tile = c->scratch.ptr; a.tile_off = (const uint64_t*)c->work.ptr; a.sum_w = (float*)c->work2.ptr;
+      }
       if ((rc = pct_bp_launch(a, max_len, c->stream))) return rc;
       unsigned long long h[4];
       if (hip_check(hipMemcpyAsync(h, c->counters.ptr, sizeof h, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;

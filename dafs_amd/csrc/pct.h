@@ -44,7 +44,11 @@ struct pct_bp_args {
   uint64_t* out_off;
   uint32_t* out_nnz;
   int* status;
-  uint32_t max_len, tile_cells;
+  // dense L x L tiles, one per sequence (tile + tile_off[x]), and the sums of the weights w_y
+  float* tile;
+  const uint64_t* tile_off;
+  float* sum_w;
+  uint32_t max_len;
 };
 
 int pct_match_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint32_t count, hipStream_t st);

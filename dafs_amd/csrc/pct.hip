@@ -59,20 +59,23 @@ struct pct_item {  // one (z, k) of a row, held by one lane of the row's group
 // of a group update the row accumulator together; the groups of a wavefront are different rows.
 template <int Q>
 struct pct_round {
-  static __device__ __forceinline__ void fetch(const pct_match_args& a, const pct_item& it, int t, uint32_t (&jc)[16], float (&pv)[16]) {
+  static __device__ __forceinline__ void fetch(const uint32_t* __restrict__ col, const float* __restrict__ val, const pct_item& it, int t, uint32_t (&jc)[16],
+                                               float (&pv)[16]) {
     const uint32_t n = row_bcast<Q>(it.n), lo = row_bcast<Q>(it.ptr_lo), hi = row_bcast<Q>(it.ptr_hi), jid = row_bcast<Q>(it.j);
     const bool ident = (lo & hi) == 0xFFFFFFFFu;
     jc[Q] = jid; pv[Q] = 1.0f;
     if ((uint32_t)t < n && !ident) {
       const uint64_t e = (((uint64_t)hi << 32) | lo) + (uint32_t)t;
-      jc[Q] = a.in.col[e]; pv[Q] = a.in.val[e];
+      jc[Q] = col[e]; pv[Q] = val[e];
     }
-    pct_round<Q + 1>::fetch(a, it, t, jc, pv);
+    pct_round<Q + 1>::fetch(col, val, it, t, jc, pv);
   }
-  static __device__ __forceinline__ void apply(const pct_match_args& a, const pct_item& it, int t, const uint32_t (&jc)[16], const float (&pv)[16], float* acc) {
+  // jlo: only columns >= jlo take part (the base-pair transform keeps i < j)
+  static __device__ __forceinline__ void apply(const uint32_t* __restrict__ col, const float* __restrict__ val, const pct_item& it, int t, uint32_t jlo,
+                                               const uint32_t (&jc)[16], const float (&pv)[16], float* acc) {
     const uint32_t n = row_bcast<Q>(it.n);
     const float pik = row_bcastf<Q>(it.pik), w = row_bcastf<Q>(it.w);
-    if ((uint32_t)t < n) acc[jc[Q]] += pik * pv[Q] * w;  // dafs.cpp:300 / :308 / :316
+    if ((uint32_t)t < n && jc[Q] >= jlo) acc[jc[Q]] += pik * pv[Q] * w;  // dafs.cpp:300 / :308 / :316, :359 / :368
     if (__any(n > 16)) {  // a b-row longer than the group: the rest of it, before the next item
       const uint32_t lo = row_bcast<Q>(it.ptr_lo), hi = row_bcast<Q>(it.ptr_hi);
       const uint64_t base = ((uint64_t)hi << 32) | lo;
@@ -81,17 +84,21 @@ struct pct_round {
       for (int o = 16; o < 64; o <<= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, o));
       for (uint32_t e0 = 16; e0 < nmax; e0 += 16) {
         wave_lds_fence();
-        if (e0 + (uint32_t)t < n) { const uint64_t e = base + e0 + (uint32_t)t; acc[a.in.col[e]] += pik * a.in.val[e] * w; }
+        if (e0 + (uint32_t)t < n) {
+          const uint64_t e = base + e0 + (uint32_t)t;
+          const uint32_t jj = col[e];
+          if (jj >= jlo) acc[jj] += pik * val[e] * w;
+        }
       }
     }
     wave_lds_fence();
-    pct_round<Q + 1>::apply(a, it, t, jc, pv, acc);
+    pct_round<Q + 1>::apply(col, val, it, t, jlo, jc, pv, acc);
   }
 };
 template <>
 struct pct_round<16> {
-  static __device__ __forceinline__ void fetch(const pct_match_args&, const pct_item&, int, uint32_t (&)[16], float (&)[16]) {}
-  static __device__ __forceinline__ void apply(const pct_match_args&, const pct_item&, int, const uint32_t (&)[16], const float (&)[16], float*) {}
+  static __device__ __forceinline__ void fetch(const uint32_t*, const float*, const pct_item&, int, uint32_t (&)[16], float (&)[16]) {}
+  static __device__ __forceinline__ void apply(const uint32_t*, const float*, const pct_item&, int, uint32_t, const uint32_t (&)[16], const float (&)[16], float*) {}
 };
 
 __global__ __launch_bounds__(256) void k_pct_rows(pct_match_args a, uint32_t pair0, uint32_t row_cap) {
@@ -215,8 +222,8 @@ __global__ __launch_bounds__(256) void k_pct_rows(pct_match_args a, uint32_t pai
       }
       uint32_t jc[16];
       float pv[16];
-      pct_round<0>::fetch(a, it, t, jc, pv);
-      pct_round<0>::apply(a, it, t, jc, pv, acc);
+      pct_round<0>::fetch(a.in.col, a.in.val, it, t, jc, pv);
+      pct_round<0>::apply(a.in.col, a.in.val, it, t, 0u, jc, pv, acc);
     }
     wave_lds_fence();
   }
@@ -312,115 +319,217 @@ __global__ __launch_bounds__(256) void k_pct_emit(pct_match_args a, uint32_t pai
   }
 }
 
-__global__ __launch_bounds__(256) void k_pct_bp(pct_bp_args a) {
-  extern __shared__ float s_mem[];
+// ---------------------------------------------------------------------------------------------
+// relax_basepairing_probability (dafs.cpp:326-375), same machinery.  Row i of sequence x receives
+//   bp[y][k][l] * mp[x][y][i][k] * mp[y][x][l][j] * w_y   for i < j, in the order y, k, l, j.
+// A group first fetches the rows mp[x][y][i] of 16 sequences y; every (y, k) then opens the row bp[y][k],
+// whose entries (l, p_kl) are the "items": each one adds the row mp[y][x][l], scaled, to the accumulator.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pct_bp_rows(pct_bp_args a, uint32_t row_cap) {
+  extern __shared__ unsigned char s_raw[];
   const uint32_t N = a.mp.nseq;
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
-  float* wy = s_mem;                              // N
-  uint32_t* rowptr = (uint32_t*)(wy + N);         // max_len + 2
-  float* acc = (float*)(rowptr + a.max_len + 2);  // tile_cells
-  __shared__ float s_sum_w;
+  const int t = (int)(tid & 15), gw = (int)(tid >> 4);
+  // per y: bases of mp[x][y] (a-side) and of mp[y][x] (c-side), and w_y
+  uint64_t* a_rp = (uint64_t*)s_raw;
+  uint64_t* a_ent = a_rp + N;
+  uint64_t* c_rp = a_ent + N;
+  uint64_t* c_ent = c_rp + N;
+  float* wy = (float*)(c_ent + N);
+  unsigned char* gbase = (unsigned char*)(wy + ((N + 1) & ~1u)) + (size_t)gw * ((size_t)row_cap * 4 + 16 * 8 + 20 * 4 + 16 * 4);
+  uint64_t* zaent = (uint64_t*)gbase;
+  uint32_t* zoff = (uint32_t*)(zaent + 16);
+  uint32_t* zid = zoff + 20;
+  float* acc = (float*)(zid + 16);
+
+  const uint32_t x = blockIdx.x;
+  const uint32_t L1 = a.mp.len[x];
+  const uint32_t row0 = blockIdx.y * PCT_ROWS_PER_WG;
+  if (row0 >= L1) return;
+  for (uint32_t y = tid; y < N; y += nt) {
+    float w = a.sim[(size_t)y * N + x];  // dafs.cpp:341-348
+    if (a.w_pct < 0.0) w *= 1.0 / N;
+    else if (y == x) w *= 1.0 - a.w_pct;
+    else w *= a.w_pct / (N - 1);
+    wy[y] = w;
+    a_rp[y] = 0; a_ent[y] = 0; c_rp[y] = 0; c_ent[y] = 0;
+    if (y != x) {
+      const uint32_t lo = x < y ? x : y, hi = x < y ? y : x;
+      const uint32_t tk = a.mp.task_of_pair[pair_id(lo, hi, N)];
+      const uint64_t rp = a.mp.rp_off[tk], ent = a.mp.pair_off[tk], nz = a.mp.pair_nnz[tk];
+      const uint64_t rp2 = rp + a.mp.len[lo] + 1, ent2 = ent + nz;  // the transposed half of the task
+      a_rp[y] = x < y ? rp : rp2; a_ent[y] = x < y ? ent : ent2;    // mp[x][y]
+      c_rp[y] = x < y ? rp2 : rp; c_ent[y] = x < y ? ent2 : ent;    // mp[y][x]
+    }
+  }
+  __syncthreads();
+  if (blockIdx.y == 0 && tid == 0) {
+    float sw = 0.0f;
+    for (uint32_t y = 0; y < N; ++y) sw += wy[y];
+    a.sum_w[x] = sw;
+  }
+  float* tile = a.tile + a.tile_off[x];
+
+  const uint32_t i = row0 + (uint32_t)gw;
+  const bool rowact = i < L1;
+  for (uint32_t j = (uint32_t)t; j < L1; j += PCT_G) acc[j] = 0.0f;
+  for (uint32_t yc = 0; yc < N; yc += PCT_G) {
+    // ---- rows mp[x][y][i] of the chunk, one lane per y (y == x: the identity row {(i, 1)})
+    uint32_t na = 0;
+    {
+      const uint32_t y = yc + (uint32_t)t;
+      uint64_t ent = 0;
+      if (rowact && y < N) {
+        if (y == x) na = 1;
+        else {
+          const uint32_t beg = a.mp.rowptr_pool[a_rp[y] + i], end = a.mp.rowptr_pool[a_rp[y] + i + 1];
+          na = end - beg;
+          ent = a_ent[y] + beg;
+        }
+      }
+      zaent[t] = ent;
+      zid[t] = y;
+    }
+    uint32_t incl = na;
+#pragma unroll
+    for (int o = 1; o < PCT_G; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o, PCT_G);
+      if (t >= o) incl += up;
+    }
+    zoff[t + 1] = incl;
+    if (t == 0) zoff[0] = 0;
+    const uint32_t T1 = row_bcast<15>(incl);
+    uint32_t T1max = T1;
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) T1max = max(T1max, (uint32_t)__shfl_xor((int)T1max, o));
+    T1max = __builtin_amdgcn_readfirstlane(T1max);
+    wave_lds_fence();
+    // ---- rounds of 16 (y, k): each lane opens bp[y][k]
+    for (uint32_t w0 = 0; w0 < T1max; w0 += PCT_G) {
+      const uint32_t tl = w0 + (uint32_t)t;
+      uint32_t my_y = 0, my_nb = 0, my_lo = 0, my_hi = 0;
+      float my_pik = 0.0f;
+      if (tl < T1) {
+        uint32_t zz = 0;
+#pragma unroll
+        for (int q = 1; q < PCT_G; ++q) zz += (tl >= zoff[q]) ? 1u : 0u;
+        my_y = zid[zz];
+        uint32_t k = i;
+        my_pik = 1.0f;
+        if (my_y != x) { const uint64_t e = zaent[zz] + (tl - zoff[zz]); k = a.mp.col[e]; my_pik = a.mp.val[e]; }
+        const row_ref b = bp_row(a.bp, my_y, k);  // (l, p_kl)
+        my_nb = b.n;
+        const uint64_t off = (uint64_t)(b.col - a.bp.col);
+        my_lo = (uint32_t)off; my_hi = (uint32_t)(off >> 32);
+      }
+      // ---- the 16 (y, k) of the round in turn: the entries of bp[y][k] are the items
+      for (int q = 0; q < PCT_G; ++q) {
+        const uint32_t nb = (uint32_t)__shfl((int)my_nb, q, PCT_G);
+        uint32_t nbmax = nb;
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) nbmax = max(nbmax, (uint32_t)__shfl_xor((int)nbmax, o));
+        nbmax = __builtin_amdgcn_readfirstlane(nbmax);
+        if (nbmax == 0) continue;
+        const uint32_t yq = (uint32_t)__shfl((int)my_y, q, PCT_G);
+        const float pik = __shfl(my_pik, q, PCT_G);
+        const uint64_t boff = ((uint64_t)(uint32_t)__shfl((int)my_hi, q, PCT_G) << 32) | (uint32_t)__shfl((int)my_lo, q, PCT_G);
+        for (uint32_t e0 = 0; e0 < nbmax; e0 += PCT_G) {
+          pct_item it;
+          it.ptr_lo = 0; it.ptr_hi = 0; it.n = 0; it.j = 0; it.pik = 0.0f; it.w = 0.0f;
+          if (e0 + (uint32_t)t < nb) {
+            const uint32_t l = a.bp.col[boff + e0 + (uint32_t)t];
+            const float pkl = a.bp.val[boff + e0 + (uint32_t)t];
+            it.pik = pkl * pik;  // p_kl * p_ik, then * p_jl * w (:359, :368)
+            it.w = wy[yq];
+            it.j = l;
+            if (yq == x) { it.n = 1; it.ptr_lo = 0xFFFFFFFFu; it.ptr_hi = 0xFFFFFFFFu; }  // mp[x][x][l] = {(l, 1)}
+            else {
+              const uint32_t cb = a.mp.rowptr_pool[c_rp[yq] + l], ce = a.mp.rowptr_pool[c_rp[yq] + l + 1];
+              const uint64_t ptr = c_ent[yq] + cb;
+              it.n = ce - cb; it.ptr_lo = (uint32_t)ptr; it.ptr_hi = (uint32_t)(ptr >> 32);
+            }
+          }
+          uint32_t jc[16];
+          float pv[16];
+          pct_round<0>::fetch(a.mp.col, a.mp.val, it, t, jc, pv);
+          pct_round<0>::apply(a.mp.col, a.mp.val, it, t, i + 1, jc, pv, acc);
+        }
+      }
+    }
+    wave_lds_fence();
+  }
+  if (rowact)
+    for (uint32_t j = (uint32_t)t; j < L1; j += PCT_G) tile[(size_t)i * L1 + j] = acc[j];
+}
+
+// thresholded upper-triangular CSR of one sequence's tile
+__global__ __launch_bounds__(256) void k_pct_bp_emit(pct_bp_args a) {
+  extern __shared__ uint32_t s_ptrs[];  // rowptr[max_len + 2]
+  __shared__ uint32_t s_part[256];
   __shared__ unsigned long long s_off;
   __shared__ int s_ok;
-
-  for (uint32_t x = blockIdx.x; x < N; x += gridDim.x) {
-    const uint32_t L1 = a.mp.len[x];
-    // dafs.cpp:341-348
-    for (uint32_t y = tid; y < N; y += nt) {
-      float w = a.sim[(size_t)y * N + x];
-      if (a.w_pct < 0.0) w *= 1.0 / N;
-      else if (y == x) w *= 1.0 - a.w_pct;
-      else w *= a.w_pct / (N - 1);
-      wy[y] = w;
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const int wave = (int)(tid >> 6), lane = (int)(tid & 63);
+  uint32_t* rowptr = s_ptrs;
+  const uint32_t x = blockIdx.x;
+  const uint32_t L1 = a.mp.len[x];
+  const float* tile = a.tile + a.tile_off[x];
+  const float sum_w = a.sum_w[x];
+  for (uint32_t i = (uint32_t)wave; i < L1; i += 4) {
+    uint32_t c = 0;
+    for (uint32_t j0 = 0; j0 < L1; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      const bool keep = j < L1 && j > i && tile[(size_t)i * L1 + j] / sum_w > PCT_CUTOFF;
+      c += (uint32_t)__popcll(__ballot(keep));
     }
+    if (lane == 0) rowptr[i + 1] = c;
+  }
+  if (tid == 0) rowptr[0] = 0;
+  __syncthreads();
+  {
+    uint32_t* arr = rowptr + 1;
+    const uint32_t n = L1;
+    const uint32_t chunk = (n + nt - 1) / nt;
+    const uint32_t b = tid * chunk < n ? tid * chunk : n, e = b + chunk < n ? b + chunk : n;
+    uint32_t sum = 0;
+    for (uint32_t k = b; k < e; ++k) sum += arr[k];
+    s_part[tid] = sum;
     __syncthreads();
     if (tid == 0) {
-      float s = 0.0f;
-      for (uint32_t y = 0; y < N; ++y) s += wy[y];
-      s_sum_w = s;
+      uint32_t run = 0;
+      for (uint32_t k = 0; k < nt; ++k) { const uint32_t v = s_part[k]; s_part[k] = run; run += v; }
     }
     __syncthreads();
-    const float sum_w = s_sum_w;
-    const uint32_t TI = min(L1, a.tile_cells / L1);
-    const uint32_t ntiles = (L1 + TI - 1) / TI;
-    const int npass = ntiles == 1 ? 1 : 2;
-    unsigned long long off = 0;
-    bool ok = true;
-
-    for (int pass = 0; pass < npass; ++pass) {
-      const bool last = pass == npass - 1;
-      for (uint32_t tile = 0; tile < ntiles; ++tile) {
-        const uint32_t i0 = tile * TI;
-        const uint32_t rows = min(TI, L1 - i0);
-        for (uint32_t c = tid; c < rows * L1; c += nt) acc[c] = 0.0f;
-        __syncthreads();
-        for (uint32_t r = tid; r < rows; r += nt) {
-          const uint32_t i = i0 + r;
-          float* arow = acc + (size_t)r * L1;
-          for (uint32_t y = 0; y < N; ++y) {
-            const float w = wy[y];
-            if (y == x) {  // mp[x][x] is the identity: k = i, p_ik = 1; j = l, p_jl = 1
-              const row_ref b = bp_row(a.bp, x, i);
-              for (uint32_t e = 0; e < b.n; ++e) {
-                const uint32_t j = b.col[e];
-                if (i < j) arow[j] += b.val[e] * 1.0f * 1.0f * w;
-              }
-            } else {
-              const row_ref ar = mp_row(a.mp, x, y, i);  // (k, p_ik) = entries (i, p_ik) of mp[y][x][k], k ascending
-              for (uint32_t ea = 0; ea < ar.n; ++ea) {
-                const uint32_t k = ar.col[ea];
-                const float p_ik = ar.val[ea];
-                const row_ref b = bp_row(a.bp, y, k);  // (l, p_kl)
-                for (uint32_t eb = 0; eb < b.n; ++eb) {
-                  const float p_kl = b.val[eb];
-                  const row_ref c = mp_row(a.mp, y, x, b.col[eb]);  // mp[y][x][l]: (j, p_jl)
-                  for (uint32_t ec = 0; ec < c.n; ++ec) {
-                    const uint32_t j = c.col[ec];
-                    if (i < j) arow[j] += p_kl * p_ik * c.val[ec] * w;
-                  }
-                }
-              }
-            }
-          }
-        }
-        __syncthreads();
-        if (pass == 0) {
-          for (uint32_t r = tid; r < rows; r += nt) {
-            uint32_t c = 0;
-            for (uint32_t j = i0 + r + 1; j < L1; ++j) c += (acc[(size_t)r * L1 + j] / sum_w > PCT_CUTOFF) ? 1 : 0;
-            rowptr[i0 + r + 1] = c;
-          }
-          __syncthreads();
-        }
-        if (pass == 0 && tile == ntiles - 1) {
-          if (tid == 0) {
-            rowptr[0] = 0;
-            for (uint32_t i = 0; i < L1; ++i) rowptr[i + 1] += rowptr[i];
-            const uint32_t n = rowptr[L1];
-            const unsigned long long o = atomicAdd(a.pool_top, (unsigned long long)n);
-            s_off = o;
-            s_ok = (o + n <= a.pool_cap) ? 1 : 0;
-            if (!s_ok) atomicExch(a.status, DAFS_HIP_EOVERFLOW);
-            a.out_off[x] = o;
-            a.out_nnz[x] = n;
-          }
-          __syncthreads();
-          off = s_off;
-          ok = s_ok != 0;
-          const uint64_t rp = a.bp.rp_off[x];  // same row-pointer layout as the input store
-          for (uint32_t i = tid; i <= L1; i += nt) a.out_rowptr[rp + i] = rowptr[i];
-        }
-        if (last && ok) {
-          for (uint32_t r = tid; r < rows; r += nt) {
-            unsigned long long pos = off + rowptr[i0 + r];
-            for (uint32_t j = i0 + r + 1; j < L1; ++j) {
-              const float v = acc[(size_t)r * L1 + j] / sum_w;
-              if (v > PCT_CUTOFF) { a.out_col[pos] = j; a.out_val[pos] = v; ++pos; }
-            }
-          }
-        }
-        __syncthreads();
+    uint32_t run = s_part[tid];
+    for (uint32_t k = b; k < e; ++k) { run += arr[k]; arr[k] = run; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const uint32_t n = rowptr[L1];
+    const unsigned long long o = atomicAdd(a.pool_top, (unsigned long long)n);
+    s_off = o;
+    s_ok = (o + n <= a.pool_cap) ? 1 : 0;
+    if (!s_ok) atomicExch(a.status, DAFS_HIP_EOVERFLOW);
+    a.out_off[x] = o;
+    a.out_nnz[x] = n;
+  }
+  __syncthreads();
+  const unsigned long long off = s_off;
+  const uint64_t rp = a.bp.rp_off[x];  // same row-pointer layout as the input store
+  for (uint32_t i = tid; i <= L1; i += nt) a.out_rowptr[rp + i] = rowptr[i];
+  if (!s_ok) return;
+  for (uint32_t i = (uint32_t)wave; i < L1; i += 4) {
+    unsigned long long pos = off + rowptr[i];
+    for (uint32_t j0 = 0; j0 < L1; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      const float v = j < L1 ? tile[(size_t)i * L1 + j] / sum_w : 0.0f;
+      const bool keep = j < L1 && j > i && v > PCT_CUTOFF;
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const unsigned long long q = pos + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        a.out_col[q] = j; a.out_val[q] = v;
       }
+      pos += (uint32_t)__popcll(m);
     }
   }
 }
@@ -450,16 +559,18 @@ int pct_match_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint32_
 }
 
 int pct_bp_launch(pct_bp_args a, uint32_t max_len, hipStream_t st) {
-  const size_t fixed = ((size_t)a.mp.nseq + ((size_t)max_len + 2)) * 4;
-  if (fixed + (size_t)max_len * 4 > kPctLdsBytes) return DAFS_HIP_ETOOLONG;
+  const uint32_t row_cap = (max_len + 15) & ~15u;
+  const size_t lds = pct_rows_lds_bytes(a.mp.nseq, row_cap);
+  if (lds > kPctLdsBytes) return DAFS_HIP_ETOOLONG;
   a.max_len = max_len;
-  a.tile_cells = (uint32_t)((kPctLdsBytes - fixed) / 4);
   static bool attr = false;
   if (!attr) {
-    if (hip_check(hipFuncSetAttribute((const void*)k_pct_bp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPctLdsBytes))) return DAFS_HIP_ELAUNCH;
+    if (hip_check(hipFuncSetAttribute((const void*)k_pct_bp_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPctLdsBytes))) return DAFS_HIP_ELAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL(k_pct_bp, dim3(a.mp.nseq), dim3(256), kPctLdsBytes, st, a);
+  hipLaunchKernelGGL(k_pct_bp_rows, dim3(a.mp.nseq, (max_len + PCT_ROWS_PER_WG - 1) / PCT_ROWS_PER_WG), dim3(256), lds, st, a, row_cap);
+  if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
+  hipLaunchKernelGGL(k_pct_bp_emit, dim3(a.mp.nseq), dim3(256), (size_t)(max_len + 2) * 4, st, a);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 
