@@ -251,7 +251,7 @@ __device__ float nuss_wave(uint32_t L, const float* __restrict__ S, const nuss_w
     if (j < L) cc[j] = 0;
   }
   float last = 0.0f, leftprev = 0.0f, score = 0.0f;
-  const int nsteps = (int)L + 63;
+  const int nsteps = (int)L + (int)((L + W - 1) / W) - 1;  // the last lane that owns a column finishes row 0 here
   for (uint32_t c = 0; c < W; ++c) Sb[c * 64 + lane] = S[(size_t)c * 64 + lane];  // step 0
   for (int s = 0; s < nsteps; ++s) {
     const int i = (int)L - 1 - (s - lane);
@@ -350,7 +350,7 @@ __device__ float nuss_wave_reg(uint32_t L, const float* S_, uint32_t* trb_, floa
   for (int c = 0; c < W; ++c) asm volatile("" : "+v"(Sc[c]));
   float last = 0.0f, leftprev = 0.0f, score = 0.0f;
   bool ovf = false;
-  const int nsteps = (int)L + 63;
+  const int nsteps = (int)L + (int)((L + W - 1) / W) - 1;  // the last lane that owns a column finishes row 0 here
   const int j0 = lane * W;
   for (int s = 0; s < nsteps; ++s) {
     const int i = (int)L - 1 - (s - lane);
@@ -481,7 +481,7 @@ __device__ float nw_wave_reg(uint32_t L1, uint32_t L2, const float* ps_, const f
 #pragma unroll
   for (int c = 0; c < W; ++c) { P[c] = 0.0f; Pc[c] = ps[(size_t)c * 64 + lane]; Qc[c] = qs[(size_t)c * 64 + lane]; np[c] = 0.0f; nq[c] = 0.0f; }
   float last = 0.0f, leftprev = 0.0f, score = 0.0f;
-  const int nsteps = (int)L1 + 63;
+  const int nsteps = (int)L1 + (int)((L2 + W) / W) - 1;  // lanes beyond column L2 have nothing to do
   uint32_t ef = 1u, es = 0u;
   if (lane == 0) { ef = env[2]; es = env[3]; }  // row 1
 #pragma unroll
@@ -615,7 +615,7 @@ __device__ float nw_wave(uint32_t L1, uint32_t L2, const float* __restrict__ ps,
     Qb[c * 64 + lane] = qs[(size_t)c * 64 + lane];
   }
   float last = 0.0f, leftprev = 0.0f, score = 0.0f;
-  const int nsteps = (int)L1 + 63;
+  const int nsteps = (int)L1 + (int)((L2 + W) / W) - 1;  // lanes beyond column L2 have nothing to do
   uint32_t ef = 1u, es = 0u;
   if (lane == 0) { ef = env[2]; es = env[3]; }  // row 1
   for (int s = 0; s < nsteps; ++s) {
