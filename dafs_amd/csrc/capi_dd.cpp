@@ -229,9 +229,17 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
                                 (((size_t)L2 * (L2 + 1) / 2 + 7) / 8 + (size_t)L2 * (64 + DD_CAP)) * 4};
         static const int order[3] = {1, 2, 0};
         nd.lds_flags = 0;
-        for (int o = 0; o < 3; ++o) {
-          const int k = order[o];
-          if (used + need[k] <= kDdLdsBudget) { used += need[k]; nd.lds_flags |= 1u << k; }
+        if (used + need[1] + need[2] <= kDdLdsBudget) {
+          for (int o = 0; o < 3; ++o) {
+            const int k = order[o];
+            if (used + need[k] <= kDdLdsBudget) { used += need[k]; nd.lds_flags |= 1u << k; }
+          }
+        } else {
+          // both folding DPs do not fit side by side: one region for the two of them, x first, then y (bit 3)
+          const uint32_t Lm = std::max(L1, L2);
+          const size_t shared = (((size_t)Lm * (Lm + 1) / 2 + 7) / 8 + (size_t)Lm * (64 + DD_CAP)) * 4;
+          if (Lm <= 64 * DD_WREG && used + shared <= kDdLdsBudget) { used += shared; nd.lds_flags |= 8u; }
+          if (used + need[0] <= kDdLdsBudget) { used += need[0]; nd.lds_flags |= 1u; }
         }
         lds[b] = used;
       }

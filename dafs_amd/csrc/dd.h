@@ -61,6 +61,7 @@ int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_
 int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st);
 int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st);
 #define DD_LMAX 4096  // longest child alignment the node kernels take (64 lanes x 64 columns; LDS row buffers)
+#define DD_WREG 8     // widest lane (columns) of the register-resident DP forms
 #define DD_CAP 4  // candidates per column kept in LDS by the fast folding DP
 static const size_t kDdLdsBudget = 156 * 1024;  // dynamic LDS of k_dd_solve (the CU has 160 KB; ~2.2 KB is static)
 int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, hipStream_t st);

@@ -315,7 +315,6 @@ __device__ float nuss_wave(uint32_t L, const float* __restrict__ S, const nuss_w
 // row, the scores and the candidate counters of the lane's columns live in registers, so a cell
 // without candidates touches LDS only to publish its value; a cell with candidates makes two LDS
 // round trips (all candidate keys/values at once, then all dp[i][k-1] at once).
-#define DD_WREG 8
 // Address-space-qualified views: the loops below must compile to ds_* / global_* instructions, not
 // flat_* ones (a flat access waits on both counters, i.e. on the prefetch of the next step as well).
 #define DD_LDS __attribute__((address_space(3)))
@@ -1028,7 +1027,16 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
     if (nd.lds_flags & 1) { trzp = w; w += nzw; }
     if (nd.lds_flags & 2) { trxp = w; w += nxw; ringx = (float*)w; w += 64 * L1; lckx = w; w += DD_CAP * L1; }
     if (nd.lds_flags & 4) { tryp = w; w += nyw; ringy = (float*)w; w += 64 * L2; lcky = w; w += DD_CAP * L2; }
+    if (nd.lds_flags & 8) {  // one region for both folding DPs, used by x and then by y
+      const uint32_t Lm = L1 > L2 ? L1 : L2;
+      trxp = tryp = w; w += nxw > nyw ? nxw : nyw;
+      ringx = ringy = (float*)w; w += 64 * Lm;
+      lckx = lcky = w; w += DD_CAP * Lm;
+    }
   }
+  const bool shared_xy = (nd.lds_flags & 8) != 0;
+  __shared__ uint32_t s_x_done;  // iteration whose x folding (DP + traceback) has released the shared region
+  if (tid == 0) s_x_done = 0xFFFFFFFFu;
   uint8_t* trz = nd.tr_z;
   if (!resume) {
     nw_init_tr(L1, L2, trz);
@@ -1052,7 +1060,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
     // packed traceback tables are filled by OR
     if (trzp) for (uint32_t e = tid; e < nzw; e += nt) trzp[e] = 0;
     if (trxp) for (uint32_t e = tid; e < nxw; e += nt) trxp[e] = 0;
-    if (tryp) for (uint32_t e = tid; e < nyw; e += nt) tryp[e] = 0;
+    if (tryp && !shared_xy) for (uint32_t e = tid; e < nyw; e += nt) tryp[e] = 0;
     // the three subproblems (dafs.cpp:1091-1093) side by side, one wavefront each, DP then traceback
     __syncthreads();
     if (wave == 0) {
@@ -1068,9 +1076,18 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
         else nuss_traceback_fast(L1, trxp, lckx, nd.x, (uint32_t*)Px);
       }
       DD_TICK(1);
+      if (shared_xy) {  // hand the region to the y folding
+        wave_lds_fence();
+        if (lane == 0) __hip_atomic_store(&s_x_done, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
     } else if (wave == 1) {
       bool slow = true;
       float sc = 0.0f;
+      if (shared_xy) {
+        while (__hip_atomic_load(&s_x_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t) __builtin_amdgcn_s_sleep(8);
+        for (uint32_t e = (uint32_t)lane; e < nyw; e += 64) tryp[e] = 0;
+        wave_lds_fence();
+      }
       if (tryp && Wy <= DD_WREG) sc = nuss_wave_fast(Wy, L2, nd.s_y, tryp, ringy, lcky, lane, &slow);
       if (slow && lane == 0 && prm.stamps) nd.info[5] += 1;
       if (slow) sc = nuss_wave(L2, nd.s_y, nd.wy, nd.trb_y, nd.trk_y, Py, Sby, ccy, lane);
