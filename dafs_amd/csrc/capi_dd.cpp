@@ -186,7 +186,7 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
 
   // ---- carve each node's block (two passes: size, then pointers) ----
   std::vector<dd_node> nodes(nnodes);
-  std::vector<size_t> lds(nnodes, 0);
+  std::vector<size_t> lds(nnodes, 0), split_lds(nnodes, 0);
   for (uint32_t b = 0; b < nnodes; ++b) {
     const dafs_node_input& ni = in[b];
     dd_node& nd = nodes[b];
@@ -242,6 +242,22 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
           if (used + need[0] <= kDdLdsBudget) { used += need[0]; nd.lds_flags |= 1u; }
         }
         lds[b] = used;
+        // split plan: each folding DP on a workgroup of its own.  Worth it when the two do not run side by side
+        // in one workgroup; the leader then keeps only the alignment DP (its LDS need is covered by `used`).
+        nd.split = 0; nd.fold_fast = 0;
+        split_lds[b] = 0;
+        if (!(nd.lds_flags & 2) || !(nd.lds_flags & 4)) {
+          size_t worst = 0;
+          const uint32_t Ls[2] = {L1, L2};
+          for (int r = 0; r < 2; ++r) {
+            const uint32_t L = Ls[r];
+            const size_t basef = ((size_t)2 * ((L + 63) / 64) * 64 + L) * 4;
+            const size_t fast = (((size_t)L * (L + 1) / 2 + 7) / 8 + (size_t)L * (64 + DD_CAP)) * 4;
+            if (L <= 64 * DD_WREG && basef + fast <= kDdLdsBudget) { nd.fold_fast |= 1u << r; worst = std::max(worst, basef + fast); }
+            else worst = std::max(worst, basef);
+          }
+          if (nd.fold_fast) split_lds[b] = std::max(worst, used);
+        }
       }
       nd.env = cv.take<uint32_t>(2 * ((size_t)L1 + 1));
       nd.px_ptr = cv.take<uint32_t>((size_t)L1 + 2); nd.px_j = cv.take<uint32_t>(XX / 2 + 2);
@@ -251,7 +267,7 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
       nd.cbp_cnt = cv.take<uint32_t>(XX / 2 + 2);
       nd.tx = cv.take<int32_t>(XX / 2 + 2); nd.ty = cv.take<int32_t>(YY / 2 + 2); nd.tz = cv.take<int32_t>(ZZ + 1);
       nd.x = cv.take<uint32_t>((size_t)L1 + 2); nd.y = cv.take<uint32_t>((size_t)L2 + 2); nd.z = cv.take<uint32_t>((size_t)L1 + 2);
-      nd.score = cv.take<float>(1); nd.info = cv.take<uint32_t>(16); nd.fstate = cv.take<float>(4);
+      nd.score = cv.take<float>(1); nd.info = cv.take<uint32_t>(16); nd.fstate = cv.take<float>(4); nd.sync = cv.take<uint32_t>(8);
       if (pass == 0) {
         cv.base = c->dd_alloc(cv.used + 256);
         if (!cv.base) return DAFS_HIP_ENOMEM;
@@ -259,6 +275,7 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
     }
     for (const region& r : fills)
       if (hip_check(hipMemsetAsync(cv.base + r.off, r.value, r.bytes, c->stream))) return DAFS_HIP_ELAUNCH;
+    if (hip_check(hipMemsetAsync(nd.sync, 0, 32, c->stream))) return DAFS_HIP_ELAUNCH;
     auto up = [&](const void* dst, const void* src, size_t bytes) {
       return bytes == 0 || !hip_check(hipMemcpyAsync((void*)dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     };
@@ -297,7 +314,7 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
   }
   if ((rc = c->d_nodes.upload(nodes.data(), nnodes, c->stream))) return rc;
   if ((rc = dd_cbp_fill_launch(c->d_nodes.ptr, nnodes, dp, c->stream))) return rc;
-  for (uint32_t b = 0; b < nnodes; ++b) c->dd_open.push_back({nodes[b], lds[b], false});
+  for (uint32_t b = 0; b < nnodes; ++b) c->dd_open.push_back({nodes[b], lds[b], split_lds[b], false});
   return DAFS_HIP_OK;
 }
 
@@ -313,13 +330,30 @@ int nodes_advance(dafs_hip_ctx* c, uint32_t n, const uint32_t* handles, dd_param
     if (on.finished) continue;
     nodes.push_back(on.nd);
     who.push_back(k);
-    lds_max = std::max(lds_max, on.lds);
   }
   if (nodes.empty()) return DAFS_HIP_OK;
+  // split mode (three workgroups per node) when the launch is small enough for all of them to be on the
+  // machine at once and some node profits; DAFS_HIP_DD_SPLIT=0 turns it off
+  static const bool split_allowed = !(getenv("DAFS_HIP_DD_SPLIT") && atoi(getenv("DAFS_HIP_DD_SPLIT")) == 0);
+  bool split = false;
+  if (split_allowed && nodes.size() * 3 <= 240)
+    for (size_t b = 0; b < nodes.size(); ++b) split = split || c->dd_open[handles[who[b]]].split_lds != 0;
+  for (size_t b = 0; b < nodes.size(); ++b) {
+    const dafs_hip_ctx::dd_open_node& on = c->dd_open[handles[who[b]]];
+    if (split && on.split_lds) {
+      nodes[b].split = 1;
+      nodes[b].lds_flags &= 1u;  // the leader keeps the alignment DP only
+      lds_max = std::max(lds_max, on.split_lds);
+      if (hip_check(hipMemsetAsync(nodes[b].sync, 0, 4, c->stream))) return DAFS_HIP_ELAUNCH;  // clear the exit mark of the last launch
+    } else {
+      nodes[b].split = 0;
+      lds_max = std::max(lds_max, on.lds);
+    }
+  }
   dp.slice = max_iterations;
   int rc;
   if ((rc = c->d_nodes.upload(nodes.data(), nodes.size(), c->stream))) return rc;
-  if ((rc = dd_solve_launch(c->d_nodes.ptr, (uint32_t)nodes.size(), dp, lds_max, c->stream))) return rc;
+  if ((rc = dd_solve_launch(c->d_nodes.ptr, (uint32_t)nodes.size(), dp, lds_max, split, c->stream))) return rc;
   std::vector<uint32_t> info(8 * nodes.size());
   for (size_t b = 0; b < nodes.size(); ++b)
     if (hip_check(hipMemcpyAsync(&info[8 * b], nodes[b].info, 32, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;

@@ -121,7 +121,7 @@ struct dafs_hip_ctx {
   // _close, in large chunks that are kept for the next phase
   struct dd_chunk { uint8_t* ptr; size_t cap, used; };
   std::vector<dd_chunk> dd_chunks;
-  struct dd_open_node { dafs::dd_node nd; size_t lds; bool finished; };
+  struct dd_open_node { dafs::dd_node nd; size_t lds, split_lds; bool finished; };
   std::vector<dd_open_node> dd_open;
   uint8_t* dd_alloc(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;

@@ -46,6 +46,11 @@ struct dd_node {
   uint32_t* info;                 // [16]: ncbp, iterations (next iteration while paused), violated, status, slow-x, slow-y,
                                   //       started, paused; [8..13] optional phase ticks
   float* fstate;                  // [4]: c, eta, previous dual value of a paused node
+  // split mode: the two folding DPs of this node run on workgroups of their own (blockIdx.y = 1, 2) next to
+  // the leader (blockIdx.y = 0, alignment DP + constraints + updates); sync[0] go / exit, [1] x done, [2] y done,
+  // [3] [4] the folding scores.  fold_fast: bit 0 / 1 the fast form of x / y fits the folder's LDS.
+  uint32_t* sync;
+  uint32_t split, fold_fast;
 };
 
 struct dd_params {
@@ -64,7 +69,7 @@ int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, h
 #define DD_WREG 8     // widest lane (columns) of the register-resident DP forms
 #define DD_CAP 4  // candidates per column kept in LDS by the fast folding DP
 static const size_t kDdLdsBudget = 156 * 1024;  // dynamic LDS of k_dd_solve (the CU has 160 KB; ~2.2 KB is static)
-int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, hipStream_t st);
+int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, bool split, hipStream_t st);
 // standalone decoders on dense device matrices (one workgroup each)
 int nussinov_launch(uint32_t L, const float* p, const float* q, float w, float th, nuss_ws ws, uint32_t* ss, float* score, hipStream_t st);
 int nw_launch(uint32_t L1, uint32_t L2, const float* p, const float* q, float th, uint32_t* env, int compute_env,

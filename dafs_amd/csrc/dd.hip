@@ -978,10 +978,77 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_cbp_fill(const dd_node* nod
 }
 
 // ------------------------------------------------------------------------------------------
+// split mode: a folding DP on a workgroup of its own.  The leader (k_dd_solve, blockIdx.y == 0) publishes
+// the iteration to run in sync[0] after the multiplier updates of the previous one are visible; the folder
+// runs DP + traceback, publishes the score and raises its counter.  All waits are bounded.
+// ------------------------------------------------------------------------------------------
+#define DD_SYNC_EXIT 0xFFFFFFFFu
+#define DD_SPIN_LIMIT (1u << 22)
+__device__ __forceinline__ uint32_t sync_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sync_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __noinline__ void dd_folder(const dd_node& nd, const dd_params& prm, uint32_t role, uint32_t t_first) {
+  extern __shared__ unsigned char s_dd[];
+  __shared__ float s_fscore;
+  __shared__ uint32_t s_go;
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const int wave = (int)(tid >> 6), lane = (int)(tid & 63);
+  const bool isx = role == 1;
+  const uint32_t L = isx ? nd.L1 : nd.L2;
+  const uint32_t W = (L + 63) / 64;
+  const float* S = isx ? nd.s_x : nd.s_y;
+  const nuss_ws& ws = isx ? nd.wx : nd.wy;
+  uint8_t* trb_g = isx ? nd.trb_x : nd.trb_y;
+  uint32_t* trk = isx ? nd.trk_x : nd.trk_y;
+  uint32_t* ss = isx ? nd.x : nd.y;
+  float* P = (float*)s_dd;
+  float* Sb = P + W * 64;
+  uint32_t* cc = (uint32_t*)(Sb + W * 64);
+  uint32_t* w = cc + L;
+  const uint32_t nw = (uint32_t)(((size_t)L * (L + 1) / 2 + 7) / 8);
+  uint32_t *trbp = nullptr, *lck = nullptr;
+  float* ring = nullptr;
+  if (nd.fold_fast & (isx ? 1u : 2u)) { trbp = w; w += nw; ring = (float*)w; w += 64 * L; lck = w; }
+  for (uint32_t it = t_first;; ++it) {
+    if (tid == 0) {
+      uint32_t g = 0, spins = 0;
+      while ((g = sync_load(&nd.sync[0])) != it + 1 && g != DD_SYNC_EXIT && ++spins < DD_SPIN_LIMIT) __builtin_amdgcn_s_sleep(16);
+      s_go = (g == it + 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_go) break;
+    for (uint32_t i = tid; i < L; i += nt) ss[i] = DD_NONE;
+    if (trbp) for (uint32_t e = tid; e < nw; e += nt) trbp[e] = 0;
+    __syncthreads();
+    if (wave == 0) {
+      bool slow = true;
+      float sc = 0.0f;
+      if (trbp && W <= DD_WREG) sc = nuss_wave_fast(W, L, S, trbp, ring, lck, lane, &slow);
+      if (slow) sc = nuss_wave(L, S, ws, trb_g, trk, P, Sb, cc, lane);
+      if (lane == 0) {
+        s_fscore = sc;
+        if (slow) nuss_traceback_b(L, trb_g, trk, ss, (uint32_t*)P);
+        else nuss_traceback_fast(L, trbp, lck, ss, (uint32_t*)P);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      nd.sync[2 + role] = __float_as_uint(s_fscore);
+      sync_store(&nd.sync[role], it + 1);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // the subgradient loop, dafs.cpp:1066-1294
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, dd_params prm) {
   const dd_node nd = nodes[blockIdx.x];
+  if (blockIdx.y != 0) {  // folding workgroups of a split node
+    if (nd.split) dd_folder(nd, prm, blockIdx.y, nd.info[6] != 0 ? nd.info[1] : 0u);
+    return;
+  }
+  const bool split = nd.split != 0;
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const uint32_t L1 = nd.L1, L2 = nd.L2;
   const uint32_t ncbp = nd.info[0];
@@ -1055,15 +1122,23 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
   uint32_t ran = 0;
   bool paused = false;
   for (t = t_first; t != prm.t_max; ++t) {
-    for (uint32_t i = tid; i < L1; i += nt) nd.x[i] = DD_NONE;
-    for (uint32_t k = tid; k < L2; k += nt) nd.y[k] = DD_NONE;
+    if (split) {
+      // every thread's multiplier updates are out (the barrier that ended the previous iteration, or the one
+      // after the initial fill); one release publishes them together with the go signal
+      if (tid == 0) sync_store(&nd.sync[0], t + 1);
+    } else {
+      for (uint32_t i = tid; i < L1; i += nt) nd.x[i] = DD_NONE;
+      for (uint32_t k = tid; k < L2; k += nt) nd.y[k] = DD_NONE;
+    }
     // packed traceback tables are filled by OR
     if (trzp) for (uint32_t e = tid; e < nzw; e += nt) trzp[e] = 0;
     if (trxp) for (uint32_t e = tid; e < nxw; e += nt) trxp[e] = 0;
     if (tryp && !shared_xy) for (uint32_t e = tid; e < nyw; e += nt) tryp[e] = 0;
     // the three subproblems (dafs.cpp:1091-1093) side by side, one wavefront each, DP then traceback
     __syncthreads();
-    if (wave == 0) {
+    if (split) {
+      // the folders are at work on their own CUs
+    } else if (wave == 0) {
       bool slow = true;
       float sc = 0.0f;
       if (trxp && Wx <= DD_WREG) sc = nuss_wave_fast(Wx, L1, nd.s_x, trxp, ringx, lckx, lane, &slow);
@@ -1080,7 +1155,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
         wave_lds_fence();
         if (lane == 0) __hip_atomic_store(&s_x_done, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-    } else if (wave == 1) {
+    } else if (wave == 1 && !split) {
       bool slow = true;
       float sc = 0.0f;
       if (shared_xy) {
@@ -1096,7 +1171,8 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
         if (slow) nuss_traceback_b(L2, nd.trb_y, nd.trk_y, nd.y, (uint32_t*)Py);
         else nuss_traceback_fast(L2, tryp, lcky, nd.y, (uint32_t*)Py);
       }
-    } else if (wave == 2) {
+    }
+    if (wave == 2) {
       float sc;
       if (Wz <= DD_WREG) sc = trzp ? nw_wave_fast<true>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, (uint8_t*)trzp, lane)
                                    : nw_wave_fast<false>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, trz, lane);
@@ -1113,7 +1189,16 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
       for (uint32_t e = tid - 192; e < npy; e += nt - 192) nd.ty[e] = 0;
       for (uint32_t e = tid - 192; e < ncz; e += nt - 192) nd.tz[e] = 0;
     }
-    if (tid == 0) s_violated = 0;
+    if (tid == 0) {
+      s_violated = 0;
+      if (split) {  // collect the two foldings (bounded wait; a folder that never answers fails the node)
+        uint32_t spins = 0;
+        while ((sync_load(&nd.sync[1]) != t + 1 || sync_load(&nd.sync[2]) != t + 1) && ++spins < DD_SPIN_LIMIT) __builtin_amdgcn_s_sleep(16);
+        if (spins >= DD_SPIN_LIMIT) s_bad = 1;
+        s_score[0] = __uint_as_float(nd.sync[3]);
+        s_score[1] = __uint_as_float(nd.sync[4]);
+      }
+    }
     __syncthreads();
     DD_TICK(2);
 
@@ -1264,6 +1349,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
     if (prm.slice && ++ran == prm.slice && t + 1 != prm.t_max) { paused = true; ++t; break; }  // to be continued
   }
   if (tid == 0) {
+    if (split) sync_store(&nd.sync[0], DD_SYNC_EXIT);  // the folders leave; a resumed launch starts them again
     nd.info[6] = 1;
     nd.info[7] = paused ? 1u : 0u;
     nd.info[1] = t;  // iterations done; while paused, the next iteration
@@ -1305,7 +1391,7 @@ int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, h
   hipLaunchKernelGGL(k_node_cbp_fill, dim3(nnodes), dim3(DD_THREADS), 0, st, d_nodes, prm);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
-int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, hipStream_t st) {
+int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, bool split, hipStream_t st) {
   if (!nnodes) return DAFS_HIP_OK;
   static bool attr = false;
   if (!attr) {
@@ -1313,7 +1399,8 @@ int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size
     attr = true;
   }
   if (lds_bytes > kDdLdsBudget) return DAFS_HIP_EINVAL;
-  hipLaunchKernelGGL(k_dd_solve, dim3(nnodes), dim3(DD_THREADS), lds_bytes, st, d_nodes, prm);
+  // split mode needs the three workgroups of a node on the machine together: the caller keeps 3 * nnodes within the CU count
+  hipLaunchKernelGGL(k_dd_solve, dim3(nnodes, split ? 3 : 1), dim3(DD_THREADS), lds_bytes, st, d_nodes, prm);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 int nussinov_launch(uint32_t L, const float* p, const float* q, float w, float th, nuss_ws ws, uint32_t* ss, float* score, hipStream_t st) {

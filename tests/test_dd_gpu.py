@@ -134,3 +134,18 @@ def test_alignments_beyond_1024_columns(oracle):
     want, (it, vi), got = _run_both(oracle, names, seqs, random_bp(seqs, 31, density=0.003), t_max=4)
     assert got.output == want
     assert len(got.rows[0]) > 1024
+
+
+def test_split_mode_and_shared_region(oracle, monkeypatch):
+    """Alignments of ~190-400 columns: the folding DPs either share one LDS region (x, then y) or, when the
+    launch is small, run on workgroups of their own next to the leader.  Both must reproduce the oracle."""
+    from dafs_amd import pipeline
+    from test_pct_gpu import random_bp
+    recs = synth.family_set(5, 240, seed=41)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    bp = random_bp(seqs, 41, density=0.01)
+    want, (it, vi), got = _run_both(oracle, names, seqs, bp, t_max=40)
+    assert got.output == want
+    monkeypatch.setenv("DAFS_HIP_DD_SPLIT", "0")  # read once per process: covers whichever mode the run above did not
+    ref = pipeline.run(names, seqs, bp=bp, t_max=40, level_sync=True)
+    assert ref.output == want and ref.dd_log == got.dd_log
