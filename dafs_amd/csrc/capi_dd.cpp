@@ -334,7 +334,8 @@ int nodes_advance(dafs_hip_ctx* c, uint32_t n, const uint32_t* handles, dd_param
   if (nodes.empty()) return DAFS_HIP_OK;
   // split mode (three workgroups per node) when the launch is small enough for all of them to be on the
   // machine at once and some node profits; DAFS_HIP_DD_SPLIT=0 turns it off
-  static const bool split_allowed = !(getenv("DAFS_HIP_DD_SPLIT") && atoi(getenv("DAFS_HIP_DD_SPLIT")) == 0);
+  const char* split_env = getenv("DAFS_HIP_DD_SPLIT");
+  const bool split_allowed = !(split_env && atoi(split_env) == 0);
   bool split = false;
   if (split_allowed && nodes.size() * 3 <= 240)
     for (size_t b = 0; b < nodes.size(); ++b) split = split || c->dd_open[handles[who[b]]].split_lds != 0;

@@ -146,6 +146,6 @@ def test_split_mode_and_shared_region(oracle, monkeypatch):
     bp = random_bp(seqs, 41, density=0.01)
     want, (it, vi), got = _run_both(oracle, names, seqs, bp, t_max=40)
     assert got.output == want
-    monkeypatch.setenv("DAFS_HIP_DD_SPLIT", "0")  # read once per process: covers whichever mode the run above did not
+    monkeypatch.setenv("DAFS_HIP_DD_SPLIT", "0")  # the same run with the foldings kept inside the leader's workgroup
     ref = pipeline.run(names, seqs, bp=bp, t_max=40, level_sync=True)
     assert ref.output == want and ref.dd_log == got.dd_log
