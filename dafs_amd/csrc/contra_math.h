@@ -60,4 +60,102 @@ __device__ __forceinline__ float contra_lpe(float x, float y) {
   return (lo > (float)(-2e20 / 2) && d < (float)(11.8624794162)) ? r : hi;
 }
 
+// ---- table-driven forms for the throughput-bound pair kernel (same polynomials, same piece limits).
+// The pieces have irregular limits, but no two limits are closer than 0.8, so a grid of step 1/2 has at
+// most one limit per cell: cell g = floor(2x) stores the number of limits at or below its start and the
+// limit inside it (or +inf); piece = base + (x >= limit).  Coefficients sit coefficient by coefficient
+// in rows 1040 bytes apart (conflict-free, and not fused into ds_read2 pairs; see pc_math.h).
+struct contra_tables {
+  float2 lcell[24];     // log(exp(x)+1): {limit inside the cell, pieces below as float bits}
+  float lk[4][260];     // k3, k2, k1, k0 of the eight cubics
+  float2 ecell[20];     // exp(x), -10 <= x < 0: cell g = floor(2 (x + 10))
+  float ek[4][260];     // seven cubics; piece 0 (x < -9.91152) is all zeros
+};
+
+__device__ __forceinline__ void contra_tables_init(contra_tables* t, int tid) {
+  if (tid != 0) return;
+  const float lim[7] = {(float)(0.6615367791), (float)(1.6320158198), (float)(2.4912588184), (float)(3.3792499610),
+                        (float)(4.4261691294), (float)(5.7890710412), (float)(7.8162726752)};
+  const float k[8][4] = {
+      {(float)(-0.0065591595), (float)(0.1276442762), (float)(0.4996554598), (float)(0.6931542306)},
+      {(float)(-0.0155157557), (float)(0.1446775699), (float)(0.4882939746), (float)(0.6958092989)},
+      {(float)(-0.0128909247), (float)(0.1301028251), (float)(0.5150398748), (float)(0.6795585882)},
+      {(float)(-0.0072142647), (float)(0.0877540853), (float)(0.6208708362), (float)(0.5909675829)},
+      {(float)(-0.0031455354), (float)(0.0467229449), (float)(0.7592532310), (float)(0.4348794399)},
+      {(float)(-0.0010110698), (float)(0.0185943421), (float)(0.8831730747), (float)(0.2523695427)},
+      {(float)(-0.0001962780), (float)(0.0046084408), (float)(0.9634431978), (float)(0.0983148903)},
+      {(float)(-0.0000113994), (float)(0.0003734731), (float)(0.9959107193), (float)(0.0149855051)}};
+  for (int g = 0; g < 24; ++g) {
+    const float lo = 0.5f * g, hi = 0.5f * (g + 1);
+    int base = 0;
+    float in = __builtin_huge_valf();
+    for (int q = 0; q < 7; ++q) {
+      if (lim[q] <= lo) ++base;
+      else if (lim[q] < hi) in = lim[q];
+    }
+    t->lcell[g] = make_float2(in, __int_as_float(base));
+  }
+  for (int q = 0; q < 8; ++q)
+    for (int c = 0; c < 4; ++c) t->lk[c][q] = k[q][c];
+  // exp: limits in increasing x; piece p holds x in [elim[p-1], elim[p])
+  const float elim[6] = {(float)(-9.91152), (float)(-5.8622823336), (float)(-3.8396630909), (float)(-2.4915033807), (float)(-1.4805375919),
+                         (float)(-0.6725053211)};
+  const float ec[7][4] = {
+      {0.0f, 0.0f, 0.0f, 0.0f},
+      {(float)(0.0000803850), (float)(0.0021627428), (float)(0.0194708555), (float)(0.0588080014)},
+      {(float)(0.0013889414), (float)(0.0244676474), (float)(0.1471290604), (float)(0.3042757740)},
+      {(float)(0.0072335607), (float)(0.0906002677), (float)(0.3983111356), (float)(0.6245959221)},
+      {(float)(0.0232410351), (float)(0.2085645908), (float)(0.6906367911), (float)(0.8682322329)},
+      {(float)(0.0573782771), (float)(0.3580258429), (float)(0.9121133217), (float)(0.9793091728)},
+      {(float)(0.1199175927), (float)(0.4815668234), (float)(0.9975991939), (float)(0.9999505077)}};
+  for (int g = 0; g < 20; ++g) {
+    const float lo = -10.0f + 0.5f * g, hi = -10.0f + 0.5f * (g + 1);
+    int base = 0;
+    float in = __builtin_huge_valf();
+    for (int q = 0; q < 6; ++q) {
+      if (elim[q] <= lo) ++base;
+      else if (elim[q] < hi) in = elim[q];
+    }
+    t->ecell[g] = make_float2(in, __int_as_float(base));
+  }
+  for (int q = 0; q < 7; ++q)
+    for (int c = 0; c < 4; ++c) t->ek[c][q] = ec[q][c];
+}
+
+typedef float contra_f2 __attribute__((ext_vector_type(2)));
+
+// two Fast_LogPlusEquals at once: (x.x (+) y.x, x.y (+) y.y); the cubic and the additions on the packed pipe
+__device__ __forceinline__ contra_f2 contra_lpe2_t(const contra_tables* t, contra_f2 x, contra_f2 y) {
+  contra_f2 hi, lo;
+  hi.x = fmaxf(x.x, y.x); hi.y = fmaxf(x.y, y.y);
+  lo.x = fminf(x.x, y.x); lo.y = fminf(x.y, y.y);
+  const contra_f2 d = hi - lo;
+  const contra_f2 d2 = d * 2.0f;
+  const unsigned ga = min((unsigned)d2.x, 23u), gb = min((unsigned)d2.y, 23u);
+  const float2 ca = t->lcell[ga], cb = t->lcell[gb];
+  const unsigned ia = (unsigned)__float_as_int(ca.y) + (d.x >= ca.x ? 1u : 0u), ib = (unsigned)__float_as_int(cb.y) + (d.y >= cb.x ? 1u : 0u);
+  const contra_f2 k3 = {t->lk[0][ia], t->lk[0][ib]}, k2 = {t->lk[1][ia], t->lk[1][ib]}, k1 = {t->lk[2][ia], t->lk[2][ib]}, k0 = {t->lk[3][ia], t->lk[3][ib]};
+  const contra_f2 r = (((k3 * d + k2) * d + k1) * d + k0) + lo;
+  contra_f2 o;
+  o.x = (lo.x > (float)(-2e20 / 2) && d.x < (float)(11.8624794162)) ? r.x : hi.x;
+  o.y = (lo.y > (float)(-2e20 / 2) && d.y < (float)(11.8624794162)) ? r.y : hi.y;
+  return o;
+}
+
+// two Fast_Exp at once (LogSpace.hpp:28-60); arguments >= 0 take the scalar path (expf, see contra_exp)
+__device__ __forceinline__ contra_f2 contra_exp2_t(const contra_tables* t, contra_f2 x) {
+  const contra_f2 s = (x + 10.0f) * 2.0f;
+  const contra_f2 sc = {fmaxf(s.x, 0.0f), fmaxf(s.y, 0.0f)};
+  const unsigned ga = min((unsigned)sc.x, 19u), gb = min((unsigned)sc.y, 19u);
+  const float2 ca = t->ecell[ga], cb = t->ecell[gb];
+  unsigned ia = (unsigned)__float_as_int(ca.y) + (x.x >= ca.x ? 1u : 0u), ib = (unsigned)__float_as_int(cb.y) + (x.y >= cb.x ? 1u : 0u);
+  ia = x.x < (float)(-9.91152) ? 0u : ia;  // also covers x < -10, where the cell index was clamped
+  ib = x.y < (float)(-9.91152) ? 0u : ib;
+  const contra_f2 k3 = {t->ek[0][ia], t->ek[0][ib]}, k2 = {t->ek[1][ia], t->ek[1][ib]}, k1 = {t->ek[2][ia], t->ek[2][ib]}, k0 = {t->ek[3][ia], t->ek[3][ib]};
+  contra_f2 r = ((k3 * x + k2) * x + k1) * x + k0;
+  if (!(x.x < 0.0f)) r.x = contra_exp(x.x);
+  if (!(x.y < 0.0f)) r.y = contra_exp(x.y);
+  return r;
+}
+
 }  // namespace dafs

@@ -33,6 +33,8 @@ __global__ __launch_bounds__(256) void k_pairhmm5(dafs_pairhmm5_args a, uint32_t
   constexpr int NG = 64 / G;
   extern __shared__ uint32_t s_dyn[];
   __shared__ float s_match[25], s_insert[5], s_single[5], s_pair[25];
+  __shared__ contra_tables s_ct;
+  contra_tables_init(&s_ct, threadIdx.x);
   if (threadIdx.x < 25) { s_match[threadIdx.x] = (&a.model.match[0][0])[threadIdx.x]; s_pair[threadIdx.x] = (&a.model.pair[0][0])[threadIdx.x]; }
   if (threadIdx.x < 5) { s_insert[threadIdx.x] = a.model.insert[threadIdx.x]; s_single[threadIdx.x] = a.model.single[threadIdx.x]; }
   __syncthreads();
@@ -117,21 +119,30 @@ __global__ __launch_bounds__(256) void k_pairhmm5(dafs_pairhmm5_args a, uint32_t
           const float aY = dY + (bm + (first ? 0.0f : pYM));
           const float a2X = d2X + (bm + (first ? 0.0f : p2XM));
           const float a2Y = d2Y + (bm + (first ? 0.0f : p2YM));
-          float m = contra_lpe(NI, aM);
-          if (!first) { m = contra_lpe(m, aX); m = contra_lpe(m, aY); m = contra_lpe(m, a2X); m = contra_lpe(m, a2Y); }
-          float x = contra_lpe(contra_lpe(contra_lpe(NI, pM[c] + (bix + pMX)), pX[c] + (bix + pXX)), pY[c] + (bix + pYX));
-          float y = contra_lpe(contra_lpe(contra_lpe(NI, lM + (biy + pMY)), lX + (biy + pXY)), lY + (biy + pYY));
-          float x2 = contra_lpe(contra_lpe(contra_lpe(NI, pM[c] + (bi2x + pM2X)), p2X[c] + (bi2x + p2X2X)), p2Y[c] + (bi2x + p2Y2X));
-          float y2 = contra_lpe(contra_lpe(contra_lpe(NI, lM + (bi2y + pM2Y)), l2X + (bi2y + p2X2Y)), l2Y + (bi2y + p2Y2Y));
+          // Seventeen Fast_LogPlusEquals per cell in the reference; the first of every chain has NEG_INF on the
+          // left and returns its argument unchanged (the lo > NEG_INF/2 test fails), the other twelve run as
+          // six packed pairs (contra_lpe2_t).  m: aM (+) aX (+) aY (+) a2X (+) a2Y; x, y, x2, y2: three terms each.
+          typedef contra_f2 f2;
+          const f2 r1 = contra_lpe2_t(&s_ct, f2{aM, pM[c] + (bix + pMX)}, f2{aX, pX[c] + (bix + pXX)});
+          const f2 r2 = contra_lpe2_t(&s_ct, f2{r1.x, r1.y}, f2{aY, pY[c] + (bix + pYX)});
+          const f2 r3 = contra_lpe2_t(&s_ct, f2{r2.x, lM + (biy + pMY)}, f2{a2X, lX + (biy + pXY)});
+          const f2 r4 = contra_lpe2_t(&s_ct, f2{r3.x, r3.y}, f2{a2Y, lY + (biy + pYY)});
+          const f2 r5 = contra_lpe2_t(&s_ct, f2{pM[c] + (bi2x + pM2X), lM + (bi2y + pM2Y)}, f2{p2X[c] + (bi2x + p2X2X), l2X + (bi2y + p2X2Y)});
+          const f2 r6 = contra_lpe2_t(&s_ct, f2{r5.x, r5.y}, f2{p2Y[c] + (bi2x + p2Y2X), l2Y + (bi2y + p2Y2Y)});
+          float m = first ? aM : r4.x;
+          float x = r2.y;
+          float y = r4.y;
+          float x2 = r6.x;
+          float y2 = r6.y;
           if (i == 0 || j == 0) {  // borders, :1005-1010: only the insert chains run along row 0 / column 0
             m = NI; x = NI; y = NI; x2 = NI; y2 = NI;
             if (i == 0 && j == 0) { m = 0.0f; x = 0.0f; y = 0.0f; x2 = 0.0f; y2 = 0.0f; }
-            else if (i == 0) {
-              y = contra_lpe(NI, lY + (biy + (j != 1 ? pYY : 0.0f)));
-              y2 = contra_lpe(NI, l2Y + (bi2y + (j != 1 ? p2Y2Y : 0.0f)));
+            else if (i == 0) {  // NEG_INF (+) v == v
+              y = lY + (biy + (j != 1 ? pYY : 0.0f));
+              y2 = l2Y + (bi2y + (j != 1 ? p2Y2Y : 0.0f));
             } else {
-              x = contra_lpe(NI, pX[c] + (bix + (i != 1 ? pXX : 0.0f)));
-              x2 = contra_lpe(NI, p2X[c] + (bi2x + (i != 1 ? p2X2X : 0.0f)));
+              x = pX[c] + (bix + (i != 1 ? pXX : 0.0f));
+              x2 = p2X[c] + (bi2x + (i != 1 ? p2X2X : 0.0f));
             }
           }
           if (!v) { m = NI; x = NI; y = NI; x2 = NI; y2 = NI; }
@@ -190,24 +201,17 @@ __global__ __launch_bounds__(256) void k_pairhmm5(dafs_pairhmm5_args a, uint32_t
           const float biy = insy + sgY, bi2y = insy + sg2Y;
           const float bm = (0.0f + s_match[xn * 5 + yn]) + sgM;
           // sources in delivery order: (i+1,j+1) match block, (i+1,j) insert-X blocks, (i,j+1) insert-Y blocks
-          float bM = NI, bX = NI, bY = NI, b2X = NI, b2Y = NI;
-          bM = contra_lpe(bM, dM + (bm + pMM));
-          bX = contra_lpe(bX, dM + (bm + pXM));
-          bY = contra_lpe(bY, dM + (bm + pYM));
-          b2X = contra_lpe(b2X, dM + (bm + p2XM));
-          b2Y = contra_lpe(b2Y, dM + (bm + p2YM));
-          bM = contra_lpe(bM, pX[c] + (bix + pMX));
-          bX = contra_lpe(bX, pX[c] + (bix + pXX));
-          bY = contra_lpe(bY, pX[c] + (bix + pYX));
-          bM = contra_lpe(bM, p2X[c] + (bi2x + pM2X));
-          b2X = contra_lpe(b2X, p2X[c] + (bi2x + p2X2X));
-          b2Y = contra_lpe(b2Y, p2X[c] + (bi2x + p2Y2X));
-          bM = contra_lpe(bM, gY + (biy + pMY));
-          bX = contra_lpe(bX, gY + (biy + pXY));
-          bY = contra_lpe(bY, gY + (biy + pYY));
-          bM = contra_lpe(bM, g2Y + (bi2y + pM2Y));
-          b2X = contra_lpe(b2X, g2Y + (bi2y + p2X2Y));
-          b2Y = contra_lpe(b2Y, g2Y + (bi2y + p2Y2Y));
+          // the first addend of every state arrives on NEG_INF and is taken as it is; the other twelve
+          // Fast_LogPlusEquals run as six packed pairs, in delivery order per state
+          typedef contra_f2 f2;
+          const float vX = pX[c], v2X = p2X[c];
+          const f2 q1 = contra_lpe2_t(&s_ct, f2{dM + (bm + pMM), dM + (bm + pXM)}, f2{vX + (bix + pMX), vX + (bix + pXX)});        // bM, bX
+          const f2 q2 = contra_lpe2_t(&s_ct, f2{dM + (bm + pYM), dM + (bm + p2XM)}, f2{vX + (bix + pYX), v2X + (bi2x + p2X2X)});    // bY, b2X
+          const f2 q3 = contra_lpe2_t(&s_ct, f2{q1.x, dM + (bm + p2YM)}, f2{v2X + (bi2x + pM2X), v2X + (bi2x + p2Y2X)});            // bM, b2Y
+          const f2 q4 = contra_lpe2_t(&s_ct, f2{q3.x, q1.y}, f2{gY + (biy + pMY), gY + (biy + pXY)});                                // bM, bX
+          const f2 q5 = contra_lpe2_t(&s_ct, f2{q2.x, q4.x}, f2{gY + (biy + pYY), g2Y + (bi2y + pM2Y)});                             // bY, bM
+          const f2 q6 = contra_lpe2_t(&s_ct, f2{q2.y, q3.y}, f2{g2Y + (bi2y + p2X2Y), g2Y + (bi2y + p2Y2Y)});                        // b2X, b2Y
+          float bM = q5.y, bX = q4.y, bY = q5.x, b2X = q6.x, b2Y = q6.y;
           if (i == L1 && j == L2) { bM = 0.0f; bX = 0.0f; bY = 0.0f; b2X = 0.0f; b2Y = 0.0f; }  // :1084
           if (!v) { bM = NI; bX = NI; bY = NI; b2X = NI; b2Y = NI; }
           dM = pM[c];
@@ -215,12 +219,15 @@ __global__ __launch_bounds__(256) void k_pairhmm5(dafs_pairhmm5_args a, uint32_t
           gY = bY; g2Y = b2Y;
           if (v) {  // ComputePosterior :1289-1305 + Clip :1308-1315
             float p = 0.0f;
-            p += contra_exp(ak[0][c] + bM - Z);
+            const contra_f2 e01 = contra_exp2_t(&s_ct, contra_f2{ak[0][c] + bM - Z, ak[1][c] + bM - Z});
+            const contra_f2 e23 = contra_exp2_t(&s_ct, contra_f2{ak[2][c] + bM - Z, ak[3][c] + bM - Z});
+            const contra_f2 e4 = contra_exp2_t(&s_ct, contra_f2{ak[4][c] + bM - Z, -20.0f});
+            p += e01.x;
             if (i > 1 || j > 1) {
-              p += contra_exp(ak[1][c] + bM - Z);
-              p += contra_exp(ak[2][c] + bM - Z);
-              p += contra_exp(ak[3][c] + bM - Z);
-              p += contra_exp(ak[4][c] + bM - Z);
+              p += e01.y;
+              p += e23.x;
+              p += e23.y;
+              p += e4.x;
             }
             const float mx = p < 0.0f ? 0.0f : p;
             slab[(size_t)(sf * W + c) * 64 + lane] = (1.0f < mx) ? 1.0f : mx;
