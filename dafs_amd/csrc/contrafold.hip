@@ -92,22 +92,43 @@ __device__ __forceinline__ float cf_fc_load(const cf_ctx& c, const float* FC, in
   return c.ring ? c.ring[((col - row) % CF_RING) * (c.L + 1) + row] : FC[c.off[row] + col];
 }
 
+// acc (+)= term(0) (+) term(1) ... (+) term(n-1), in that order (Fast_LogPlusEquals is not associative).
+// The addends are table loads from HBM/L2; sixteen of them are fetched while the previous sixteen are
+// being folded, so the chain of log-sum-exps rarely waits for memory.
+#define CF_FOLD 16
+template <class F>
+__device__ __forceinline__ float cf_fold(float acc, int n, F term) {
+  int k = 0;
+  if (n >= CF_FOLD) {
+    float nx[CF_FOLD];
+#pragma unroll
+    for (int u = 0; u < CF_FOLD; ++u) nx[u] = term(u);
+    for (; k + 2 * CF_FOLD <= n; k += CF_FOLD) {
+      float cur[CF_FOLD];
+#pragma unroll
+      for (int u = 0; u < CF_FOLD; ++u) { cur[u] = nx[u]; nx[u] = term(k + CF_FOLD + u); }
+#pragma unroll
+      for (int u = 0; u < CF_FOLD; ++u) acc = contra_lpe(acc, cur[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < CF_FOLD; ++u) acc = contra_lpe(acc, nx[u]);
+    k += CF_FOLD;
+  }
+  for (; k + 4 <= n; k += 4) {
+    const float a0 = term(k), a1 = term(k + 1), a2 = term(k + 2), a3 = term(k + 3);
+    acc = contra_lpe(contra_lpe(contra_lpe(contra_lpe(acc, a0), a1), a2), a3);
+  }
+  for (; k < n; ++k) acc = contra_lpe(acc, term(k));
+  return acc;
+}
+
 __device__ void cf_inside_cell(const cf_ctx& c, int i, int j, float* FCi, float* FMi, float* FM1i) {
   const int L = c.L;
   const int* off = c.off;
   float FM2i = CONTRA_NEG_INF;
   if (i + 2 <= j) {
-    // sequential fold over k (:3392-3405); loads of the next four addends are issued before the
-    // dependent log-sum-exp chain consumes the current four
-    int k = i + 1;
-    for (; k + 4 <= j; k += 4) {
-      const float a0 = FM1i[off[i] + k] + FMi[off[k] + j];
-      const float a1 = FM1i[off[i] + k + 1] + FMi[off[k + 1] + j];
-      const float a2 = FM1i[off[i] + k + 2] + FMi[off[k + 2] + j];
-      const float a3 = FM1i[off[i] + k + 3] + FMi[off[k + 3] + j];
-      FM2i = contra_lpe(contra_lpe(contra_lpe(contra_lpe(FM2i, a0), a1), a2), a3);
-    }
-    for (; k < j; k++) FM2i = contra_lpe(FM2i, FM1i[off[i] + k] + FMi[off[k] + j]);
+    // sequential fold over k = i+1 .. j-1 (:3392-3405)
+    FM2i = cf_fold(FM2i, j - i - 1, [&](int u) { const int k = i + 1 + u; return FM1i[off[i] + k] + FMi[off[k] + j]; });
   }
   float fc = CONTRA_NEG_INF;
   const bool closing = (0 < i && j < L && cf_allow_paired(c, i, j + 1));
@@ -166,15 +187,7 @@ __device__ void cf_outside_cell(const cf_ctx& c, int a, int b, const float* FCi,
   // ---- FMo[a][b]: block 4 of sources (i,b), i = 0..a-1 (:4040-4068), then block 1 of source (a,b+1) (:3770-3777)
   float fmo = CONTRA_NEG_INF;
   if (a < b) {
-    int i = 0;
-    for (; i + 4 <= a; i += 4) {
-      const float t0 = FM2o[off[i] + b] + FM1i[off[i] + a];
-      const float t1 = FM2o[off[i + 1] + b] + FM1i[off[i + 1] + a];
-      const float t2 = FM2o[off[i + 2] + b] + FM1i[off[i + 2] + a];
-      const float t3 = FM2o[off[i + 3] + b] + FM1i[off[i + 3] + a];
-      fmo = contra_lpe(contra_lpe(contra_lpe(contra_lpe(fmo, t0), t1), t2), t3);
-    }
-    for (; i < a; i++) fmo = contra_lpe(fmo, FM2o[off[i] + b] + FM1i[off[i] + a]);
+    fmo = cf_fold(fmo, a, [&](int i) { return FM2o[off[i] + b] + FM1i[off[i] + a]; });
   }
   if (0 < a && a + 2 <= b + 1 && b + 1 < L && cf_unpaired_pos(c, b + 1)) fmo = contra_lpe(fmo, FMo[off[a] + b + 1] + MULTI_UNPAIRED);
   FMo[off[a] + b] = fmo;
@@ -228,15 +241,7 @@ __device__ void cf_outside_cell(const cf_ctx& c, int a, int b, const float* FCi,
   float fm1o = CONTRA_NEG_INF;
   if (0 < a - 1 && a - 1 + 2 <= b && b < L && cf_unpaired_pos(c, a)) fm1o = contra_lpe(fm1o, FM1o[off[a - 1] + b] + MULTI_UNPAIRED);
   if (a < b) {
-    int j = L;
-    for (; j - 4 >= b; j -= 4) {
-      const float t0 = FM2o[off[a] + j] + FMi[off[b] + j];
-      const float t1 = FM2o[off[a] + j - 1] + FMi[off[b] + j - 1];
-      const float t2 = FM2o[off[a] + j - 2] + FMi[off[b] + j - 2];
-      const float t3 = FM2o[off[a] + j - 3] + FMi[off[b] + j - 3];
-      fm1o = contra_lpe(contra_lpe(contra_lpe(contra_lpe(fm1o, t0), t1), t2), t3);
-    }
-    for (; j > b; j--) fm1o = contra_lpe(fm1o, FM2o[off[a] + j] + FMi[off[b] + j]);
+    fm1o = cf_fold(fm1o, L - b, [&](int u) { const int j = L - u; return FM2o[off[a] + j] + FMi[off[b] + j]; });
   }
   const bool live = (0 < a && a + 2 <= b && b < L);
   if (live) fm1o = contra_lpe(fm1o, fmo);
