@@ -369,6 +369,16 @@ __device__ float nuss_wave_reg(uint32_t L, const float* S_, uint32_t* trb_, floa
     if (rowv && (uint32_t)(i - j0) < (uint32_t)W) *(DD_LDS float*)(rrow + ui * 4) = 0.0f;  // dp[i][i], read by candidates of row i+1
     const bool row0 = rowv && i == 0;
     const uint32_t knew = ui ? (ui - 1) * 4 : 0u;
+    // A candidate (k, j) has k <= j - 3, so the column k-1 it reads lies at least four columns to the left of
+    // j: with up to four columns per lane it is never one of this lane's own columns of this step, and all
+    // the dp[i][k-1] of the step can be fetched in one round trip before the first cell.
+    float dkall[W <= 4 ? W : 1][DD_CAP];
+    if (W <= 4) {
+#pragma unroll
+      for (int c = 0; c < (W <= 4 ? W : 1); ++c)
+#pragma unroll
+        for (int x = 0; x < DD_CAP; ++x) dkall[c][x] = *(DD_LDS const float*)(rrow + koff[c][x]);
+    }
 #pragma unroll
     for (int c = 0; c < W; ++c) {
       const int j = j0 + c, d = d0 + c;
@@ -386,7 +396,7 @@ __device__ float nuss_wave_reg(uint32_t L, const float* S_, uint32_t* trb_, floa
       const uint32_t nc = n[c];
       float dk[DD_CAP];
 #pragma unroll
-      for (int x = 0; x < DD_CAP; ++x) dk[x] = *(DD_LDS const float*)(rrow + koff[c][x]);  // all dp[i][k-1] in one round trip
+      for (int x = 0; x < DD_CAP; ++x) dk[x] = (W <= 4) ? dkall[c][x] : *(DD_LDS const float*)(rrow + koff[c][x]);  // all dp[i][k-1] in one round trip
 #pragma unroll
       for (int x = DD_CAP - 1; x >= 0; --x) {      // bifurcations, oldest candidate first (:245-255)
         const float cx = dk[x] + cvs[c][x];
