@@ -104,6 +104,7 @@ _make_brackets = _sig("dafs_hip_make_brackets", None, [C.c_uint32, C.c_void_p, C
 _dd_default_params = _sig("dafs_hip_dd_default_params", None, [C.POINTER(DDParams)])
 _solve_nodes = _sig("dafs_hip_solve_nodes", C.c_int,
                     [C.c_void_p, C.c_uint32, C.POINTER(NodeInput), C.POINTER(DDParams), C.POINTER(NodeOutput)])
+_set_mp = _sig("dafs_hip_set_mp", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
 _nodes_open = _sig("dafs_hip_nodes_open", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(NodeInput), C.POINTER(DDParams), C.c_void_p])
 _nodes_advance = _sig("dafs_hip_nodes_advance", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(DDParams), C.c_uint32, C.c_void_p])
 _nodes_result = _sig("dafs_hip_nodes_result", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(NodeOutput)])
@@ -300,6 +301,13 @@ class Context:
         check(_solve_nodes(self._h, n, ins, C.byref(prm), outs))
         return [dict(x=k[4], y=k[5], z=k[6], score=np.float32(outs[b].score), ncbp=outs[b].ncbp,
                      iterations=outs[b].iterations, violated=outs[b].violated) for b, k in enumerate(keep)]
+
+    def set_mp(self, nnz, rowptr, col, val):
+        """Supplied matching probabilities (--align-aux, or the shards of several GPUs after their all-gather): per
+        pair x<y in row-major order nnz[p], then len[x]+1 relative row pointers, then the (col, val) entries."""
+        nnz = np.ascontiguousarray(nnz, np.uint32); rowptr = np.ascontiguousarray(rowptr, np.uint32)
+        col = np.ascontiguousarray(col, np.uint32); val = np.ascontiguousarray(val, np.float32)
+        check(_set_mp(self._h, nnz.ctypes.data, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data))
 
     # --- resident nodes (no level barrier) ---
     def nodes_open(self, nodes, prm):

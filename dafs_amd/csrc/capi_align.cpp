@@ -8,6 +8,7 @@
 
 #include "../../include/dafs_hip.h"
 #include "ctx.h"
+#include "pct.h"
 #include "hip_util.h"
 
 using namespace dafs;
@@ -156,6 +157,102 @@ extern "C" int dafs_hip_align_posteriors(dafs_hip_ctx* c, int model, float th, u
     cap = std::max<uint64_t>(host_cnt[0], cap * 2);  // pool_top kept counting: exact requirement
   }
   return DAFS_HIP_EOVERFLOW;
+}
+
+// AUXAlign::calculate (src/align.cpp:204-246, --align-aux) and the hand-over point after an all-gather of
+// shards: the caller supplies the rows of mp[x][y] for every pair x < y (row-major pair order); the
+// transposes (transpose_mp, dafs.cpp:155-167) are laid out here and the similarity scores
+// (calculate_similarity_score, :713-764, :1813-1819) are computed on the device.
+extern "C" int dafs_hip_set_mp(dafs_hip_ctx* c, const uint32_t* nnz, const uint32_t* rowptr, const uint32_t* col, const float* val) {
+  if (!c || c->len.size() < 2 || !nnz || !rowptr || !col || !val) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  const uint32_t n = (uint32_t)c->len.size();
+  const uint64_t np = (uint64_t)n * (n - 1) / 2;
+  mp_store& st = c->mp[0];
+  st.valid = false;
+  c->mp[1].valid = false;
+  c->cur_mp = 0;
+  c->sim.clear();
+  st.pair_x.resize(np); st.pair_y.resize(np); st.task_of_pair.resize(np); st.rp_by_pair.resize(np);
+  st.n_tasks = np;
+  std::vector<uint64_t> pair_off(np);
+  uint64_t rp_total = 0, ent_total = 0, p = 0;
+  for (uint32_t x = 0; x < n; ++x)
+    for (uint32_t y = x + 1; y < n; ++y, ++p) {
+      st.pair_x[p] = x; st.pair_y[p] = y; st.task_of_pair[p] = (uint32_t)p;
+      st.rp_by_pair[p] = rp_total;
+      pair_off[p] = ent_total;
+      rp_total += (uint64_t)c->len[x] + 1 + c->len[y] + 1;
+      ent_total += 2ull * nnz[p];
+    }
+  std::vector<uint32_t> h_rp(rp_total), h_col(ent_total + 1);
+  std::vector<float> h_val(ent_total + 1);
+  uint64_t rin = 0, ein = 0;
+  std::vector<uint32_t> cnt;
+  for (p = 0; p < np; ++p) {
+    const uint32_t L1 = c->len[st.pair_x[p]], L2 = c->len[st.pair_y[p]], m = nnz[p];
+    const uint32_t* rp = rowptr + rin;
+    if (rp[0] != 0 || rp[L1] != m) return DAFS_HIP_EINVAL;
+    uint32_t* orp = h_rp.data() + st.rp_by_pair[p];
+    uint32_t* ocol = h_col.data() + pair_off[p];
+    float* oval = h_val.data() + pair_off[p];
+    // rows of mp[x][y] as given (columns ascending within a row)
+    for (uint32_t i = 0; i <= L1; ++i) orp[i] = rp[i];
+    cnt.assign((size_t)L2 + 1, 0);
+    for (uint32_t i = 0; i < L1; ++i) {
+      if (rp[i + 1] < rp[i] || rp[i + 1] > m) return DAFS_HIP_EINVAL;
+      for (uint32_t e = rp[i]; e < rp[i + 1]; ++e) {
+        const uint32_t j = col[ein + e];
+        if (j >= L2 || (e > rp[i] && col[ein + e - 1] >= j)) return DAFS_HIP_EINVAL;
+        ocol[e] = j; oval[e] = val[ein + e];
+        ++cnt[j + 1];
+      }
+    }
+    // rows of mp[y][x]: a counting sort by column keeps the rows of one column in ascending order
+    uint32_t* trp = orp + L1 + 1;
+    trp[0] = 0;
+    for (uint32_t j = 0; j < L2; ++j) trp[j + 1] = trp[j] + cnt[j + 1];
+    for (uint32_t j = 0; j < L2; ++j) cnt[j] = trp[j];
+    for (uint32_t i = 0; i < L1; ++i)
+      for (uint32_t e = rp[i]; e < rp[i + 1]; ++e) {
+        const uint32_t w = cnt[col[ein + e]]++;
+        ocol[m + w] = i; oval[m + w] = val[ein + e];
+      }
+    rin += (uint64_t)L1 + 1;
+    ein += m;
+  }
+  int rc;
+  st.rp_total = rp_total;
+  st.pool_used = ent_total;
+  st.pool_cap_hint = std::max<uint64_t>(st.pool_cap_hint, ent_total);
+  std::vector<uint32_t> h_nnz(nnz, nnz + np);
+  if ((rc = st.rowptr_pool.upload(h_rp.data(), rp_total, c->stream))) return rc;
+  if ((rc = st.col.upload(h_col.data(), ent_total + 1, c->stream))) return rc;
+  if ((rc = st.val.upload(h_val.data(), ent_total + 1, c->stream))) return rc;
+  if ((rc = st.pair_off.upload(pair_off.data(), np, c->stream))) return rc;
+  if ((rc = st.pair_nnz.upload(h_nnz.data(), np, c->stream))) return rc;
+  if ((rc = st.rp_off.upload(st.rp_by_pair.data(), np, c->stream))) return rc;
+  if ((rc = st.d_task_of_pair.upload(st.task_of_pair.data(), np, c->stream))) return rc;
+  if ((rc = c->d_pair_x.upload(st.pair_x.data(), np, c->stream))) return rc;
+  if ((rc = c->d_pair_y.upload(st.pair_y.data(), np, c->stream))) return rc;
+  // similarity scores
+  const uint32_t max_len = c->max_len();
+  if ((rc = c->task_sim.reserve(np))) return rc;
+  if ((rc = c->scratch.reserve(2 * ((size_t)max_len + 1) * np))) return rc;
+  float* row_dp = c->scratch.ptr;
+  int* row_tr = (int*)(c->scratch.ptr + ((size_t)max_len + 1) * np);
+  if ((rc = mp_sim_launch(st.view(c->d_len.ptr, n), c->d_pair_x.ptr, c->d_pair_y.ptr, (uint32_t)np, c->task_sim.ptr, row_dp, row_tr, c->stream))) return rc;
+  std::vector<float> ts(np);
+  if ((rc = c->task_sim.download(ts.data(), np))) return rc;
+  c->sim.assign((size_t)n * n, 0.0f);
+  for (uint32_t i = 0; i < n; ++i) c->sim[(size_t)i * n + i] = 1.0f;
+  for (p = 0; p < np; ++p) {
+    c->sim[(size_t)st.pair_x[p] * n + st.pair_y[p]] = ts[p];
+    c->sim[(size_t)st.pair_y[p] * n + st.pair_x[p]] = ts[p];
+  }
+  if ((rc = c->d_sim.upload(c->sim.data(), c->sim.size(), c->stream))) return rc;
+  st.valid = true;
+  return DAFS_HIP_OK;
 }
 
 extern "C" int dafs_hip_mp_result_size(dafs_hip_ctx* c, int relaxed, uint64_t* npairs, uint64_t* total_nnz, uint64_t* total_rowptr) {

@@ -355,6 +355,54 @@ void save_fold_aux(dafs_hip_ctx* ctx, const std::string& file, const std::vector
     r += fa[x].size() + 1;
   }
 }
+// --align-aux reader, reference src/align.cpp:204-246 ("> x y" then "i k:p k:p ...", all 1-based); the rows go to
+// the device through dafs_hip_set_mp, which also lays out the transposes and computes the similarity scores
+void load_align_aux(dafs_hip_ctx* ctx, const std::string& file, const std::vector<Fasta>& fa) {
+  std::ifstream is(file.c_str());
+  if (!is.is_open()) throw strerror(errno);
+  const uint N = (uint)fa.size();
+  std::vector<std::vector<std::vector<std::vector<std::pair<uint, float> > > > > mp(N);  // [x][y][i] -> (k, p)
+  for (uint x = 0; x < N; ++x) {
+    mp[x].resize(N);
+    for (uint y = x + 1; y < N; ++y) mp[x][y].resize(fa[x].size());
+  }
+  std::string s, t;
+  uint x = 0, y = 0;
+  while (std::getline(is, s)) {
+    if (s.empty()) continue;
+    std::istringstream ss(s);
+    if (s[0] == '>') {
+      ss >> t >> x >> y;
+      if (!(x < y && x >= 1 && y <= N)) throw "--align-aux: bad pair header";
+    } else {
+      uint i = 0, k = 0;
+      float pr = 0;
+      ss >> i;
+      if (x == 0 || i < 1 || i > fa[x - 1].size()) throw "--align-aux: bad row index";
+      while (ss >> t)
+        if (sscanf(t.c_str(), "%u:%f", &k, &pr) == 2) {
+          if (k < 1 || k > fa[y - 1].size()) throw "--align-aux: bad column index";
+          mp[x - 1][y - 1][i - 1].push_back(std::make_pair(k - 1, pr));
+        }
+    }
+  }
+  std::vector<uint32_t> nnz, rowptr, col;
+  std::vector<float> val;
+  for (uint a = 0; a < N; ++a)
+    for (uint b = a + 1; b < N; ++b) {
+      uint32_t run = 0;
+      rowptr.push_back(0);
+      for (const auto& row : mp[a][b]) {
+        for (const auto& e : row) { col.push_back(e.first); val.push_back(e.second); }
+        run += (uint32_t)row.size();
+        rowptr.push_back(run);
+      }
+      nnz.push_back(run);
+    }
+  if (col.empty()) { col.push_back(0); val.push_back(0.0f); }
+  check(dafs_hip_set_mp(ctx, nnz.data(), rowptr.data(), col.data(), val.data()));
+}
+
 void save_align_aux(dafs_hip_ctx* ctx, const std::string& file, const std::vector<Fasta>& fa) {
   uint64_t np = 0, nnz = 0, nrp = 0;
   check(dafs_hip_mp_result_size(ctx, 0, &np, &nnz, &nrp));
@@ -383,7 +431,6 @@ int run(const Options& o) {
   if (o.align_model == "ProbCons") align_model = DAFS_ALIGN_PROBCONS;
   else if (o.align_model == "CONTRAlign") align_model = DAFS_ALIGN_CONTRALIGN;
   else throw "Unknown alignment model: " + o.align_model;
-  if (!o.align_aux.empty()) throw "--align-aux is not supported by this build (use --save-align-aux to export)";
   if (o.fold_aux.empty()) {
     if (o.fold_model == "Boltzmann" || o.fold_model == "Vienna")
       throw "Folding model " + o.fold_model + " needs ViennaRNA, which this build does not contain; use -s CONTRAfold or --fold-aux";
@@ -425,7 +472,8 @@ int run(const Options& o) {
   std::vector<node_t> tree(1, std::make_pair(0.0f, std::make_pair(-1u, -1u)));
   if (N > 1) {
     // matching probabilities, transposes, similarities (:1796-1819), PCTs (:1822-1827), tree (:1830)
-    check(dafs_hip_align_posteriors(ctx, align_model, o.align_th, 0, 0));
+    if (!o.align_aux.empty()) load_align_aux(ctx, o.align_aux, fa);
+    else check(dafs_hip_align_posteriors(ctx, align_model, o.align_th, 0, 0));
     if (!o.save_align_aux.empty()) save_align_aux(ctx, o.save_align_aux, fa);
     std::vector<float> sim((size_t)N * N);
     check(dafs_hip_get_sim(ctx, sim.data()));

@@ -53,5 +53,8 @@ struct pct_bp_args {
 
 int pct_match_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint32_t count, hipStream_t st);
 int pct_bp_launch(pct_bp_args a, uint32_t max_len, hipStream_t st);
+// similarity scores of all pairs from a stored matching-probability set; row_dp / row_tr: (max_len + 1) * npairs words each
+int mp_sim_launch(mp_store_dev in, const uint32_t* pair_x, const uint32_t* pair_y, uint32_t npairs, float* task_sim, float* row_dp, int* row_tr,
+                  hipStream_t st);
 
 }  // namespace dafs

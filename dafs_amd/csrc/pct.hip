@@ -534,6 +534,54 @@ __global__ __launch_bounds__(256) void k_pct_bp_emit(pct_bp_args a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// calculate_similarity_score (dafs.cpp:713-764) from stored rows, for matching probabilities that
+// were supplied rather than computed (dafs_hip_set_mp): one thread per pair, the previous DP row
+// of all pairs interleaved in scratch so that the threads of a wavefront touch neighbouring words.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mp_sim(mp_store_dev in, const uint32_t* pair_x, const uint32_t* pair_y, uint32_t npairs, float* task_sim,
+                                                float* row_dp, int* row_tr) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npairs) return;
+  const uint32_t x = pair_x[p], y = pair_y[p];
+  const uint32_t L1 = in.len[x], L2 = in.len[y];
+  for (uint32_t j = 0; j <= L2; ++j) { row_dp[(size_t)j * npairs + p] = 0.0f; row_tr[(size_t)j * npairs + p] = 0; }
+  float dp = 0.0f;
+  int tr = 0;
+  for (uint32_t i = 1; i <= L1; ++i) {
+    const row_ref r = mp_row(in, x, y, i - 1);
+    uint32_t e = 0;
+    float ddp = 0.0f, ldp = 0.0f;  // (i-1, j-1) and (i, j-1); column 0 is the border
+    int dtr = 0, ltr = 0;
+    for (uint32_t j = 1; j <= L2; ++j) {
+      const float udp = row_dp[(size_t)j * npairs + p];
+      const int utr = row_tr[(size_t)j * npairs + p];
+      const bool entry = e < r.n && r.col[e] == j - 1;
+      if (entry) {
+        dp = ddp + r.val[e]; tr = dtr + 1;
+        if (dp < ldp) { dp = ldp; tr = ltr + 1; }
+        if (dp < udp) { dp = udp; tr = utr + 1; }
+        ++e;
+      } else {
+        dp = ldp; tr = ltr + 1;
+        if (dp < udp) { dp = udp; tr = utr + 1; }
+      }
+      ddp = udp; dtr = utr;
+      row_dp[(size_t)j * npairs + p] = dp;
+      row_tr[(size_t)j * npairs + p] = tr;
+      ldp = dp; ltr = tr;
+    }
+  }
+  task_sim[p] = dp / (float)tr;  // dafs.cpp:763
+}
+
+int mp_sim_launch(mp_store_dev in, const uint32_t* pair_x, const uint32_t* pair_y, uint32_t npairs, float* task_sim, float* row_dp, int* row_tr,
+                  hipStream_t st) {
+  if (!npairs) return DAFS_HIP_OK;
+  hipLaunchKernelGGL(k_mp_sim, dim3((npairs + 255) / 256), dim3(256), 0, st, in, pair_x, pair_y, npairs, task_sim, row_dp, row_tr);
+  return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
+}
+
 static const size_t kPctLdsBytes = 150 * 1024;  // leave room for the static LDS and alignment
 
 size_t pct_rows_lds_bytes(uint32_t nseq, uint32_t row_cap) {

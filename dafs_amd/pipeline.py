@@ -85,9 +85,10 @@ class Result:
 
 
 def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25, w_pct_s=0.25, th_a=0.01,
-        th_s=0.2, th_s1=None, align_model=capi.ALIGN_PROBCONS, force_iters=0, timers=None, level_sync=False, slice_iters=64):
+        th_s=0.2, th_s1=None, align_model=capi.ALIGN_PROBCONS, force_iters=0, timers=None, level_sync=False, slice_iters=64,
+        mp=None):
     """The whole run.  bp: per-sequence (rowptr, col, val) base-pairing rows (--fold-aux); None
-    computes them with the device fold model."""
+    computes them with the device fold model.  mp: supplied matching probabilities (--align-aux), see Context.set_mp."""
     import time
     own = ctx is None
     if own:
@@ -100,7 +101,10 @@ def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25
     else:
         ctx.fold_posteriors(0.01)
     t.append(time.perf_counter())
-    ctx.align_posteriors(align_model, th_a, fetch=False)
+    if mp is not None:
+        ctx.set_mp(*mp)  # (nnz, rowptr, col, val) of every pair, --align-aux
+    else:
+        ctx.align_posteriors(align_model, th_a, fetch=False)
     t.append(time.perf_counter())
     sim = ctx.sim()
     ctx.consistency(w_pct_a, w_pct_s)

@@ -174,7 +174,13 @@ int dafs_hip_align_fetch(dafs_hip_ctx* ctx, uint32_t* pair_x, uint32_t* pair_y, 
 int dafs_hip_mp_result_size(dafs_hip_ctx* ctx, int relaxed, uint64_t* npairs, uint64_t* total_nnz, uint64_t* total_rowptr);
 int dafs_hip_mp_fetch(dafs_hip_ctx* ctx, int relaxed, uint32_t* pair_x, uint32_t* pair_y, uint32_t* nnz,
                       uint32_t* rowptr, uint32_t* col, float* val);
-/* sim_ (src/dafs.cpp:1813-1819): N*N floats, unit diagonal; needs a full-pair-set align_posteriors. */
+/* Supplied matching probabilities instead of a model: AUXAlign::calculate (src/align.cpp:204-246, --align-aux), and
+ * the hand-over after an all-gather of shards.  For every pair x < y in row-major order: nnz[p] entries, len[x]+1 row
+ * pointers relative to the pair's first entry (concatenated), then all (col ascending within a row, val) entries
+ * concatenated.  Lays out the transposes (transpose_mp, src/dafs.cpp:155-167) and computes the similarity scores
+ * (calculate_similarity_score, :713-764) on the device. */
+int dafs_hip_set_mp(dafs_hip_ctx* ctx, const uint32_t* nnz, const uint32_t* rowptr, const uint32_t* col, const float* val);
+/* sim_ (src/dafs.cpp:1813-1819): N*N floats, unit diagonal; needs a full-pair-set align_posteriors or dafs_hip_set_mp. */
 int dafs_hip_get_sim(dafs_hip_ctx* ctx, float* sim);
 
 /* ------------------------------------------------------------------------------------------

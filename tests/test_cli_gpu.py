@@ -84,6 +84,22 @@ def test_fold_aux_round_trip(tmp_path):
     assert first[0] == "> 1 2" and first[1].startswith("1 1:0.661191404")
 
 
+def test_align_aux_round_trip(tmp_path):
+    """--align-aux (AUXAlign, src/align.cpp:204-246): supplied rows reproduce the run that exported them -- the
+    transposes and the similarity scores are rebuilt from the rows alone (dafs_hip_set_mp)."""
+    recs = synth.family_set(7, 70, seed=15)
+    fa = tmp_path / "f.fa"
+    fa.write_text(synth.to_fasta(recs))
+    aux = tmp_path / "mp.aux"
+    rc, out1, err = run_cli("--save-align-aux", str(aux), str(fa))
+    assert rc == 0, err
+    rc, out2, err = run_cli("--align-aux", str(aux), str(fa))
+    assert rc == 0, err
+    assert out1 == out2
+    rc, out3, err = run_cli("-a", "CONTRAlign", "--align-aux", str(aux), str(fa))  # the model is not consulted
+    assert rc == 0 and out3 == out1, err
+
+
 def test_single_sequence_and_refinement(tmp_path):
     one = tmp_path / "one.fa"
     one.write_text(">only\nGGGAAACCCUUUAGGGCCC\n")

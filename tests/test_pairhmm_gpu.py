@@ -152,3 +152,29 @@ def test_whole_run_contralign(oracle):
     pl.phase1(); pl.phase2()
     assert got.output == pl.output()
     pl.close()
+
+
+def test_set_mp_rebuilds_transposes_and_similarity():
+    """dafs_hip_set_mp: from the forward rows alone the store equals the one the pair kernel wrote (transposed rows,
+    similarity scores), so everything downstream is unchanged."""
+    from dafs_amd import capi, synth
+    recs = synth.family_set(9, 80, seed=3) + synth.random_set(3, 55, seed=4)
+    seqs = [r[1] for r in recs]
+    a = capi.Context(0)
+    a.set_sequences(seqs)
+    ref = a.align_posteriors()
+    sim = a.sim()
+    nnz, rps, cols, vals = [], [], [], []
+    for p in range(len(ref)):
+        rp, col, val = ref.csr(p)
+        nnz.append(len(col)); rps.append(rp); cols.append(col); vals.append(val)
+    b = capi.Context(0)
+    b.set_sequences(seqs)
+    b.set_mp(np.array(nnz, np.uint32), np.concatenate(rps), np.concatenate(cols), np.concatenate(vals))
+    assert np.array_equal(b.sim().view(np.uint32), sim.view(np.uint32))
+    got = b.mp(0)
+    for p in range(len(ref)):
+        for tr in (False, True):
+            for u, v in zip(ref.csr(p, tr), got.csr(p, tr)):
+                assert np.array_equal(np.asarray(u).view(np.uint32), np.asarray(v).view(np.uint32)), (p, tr)
+    a.close(); b.close()
