@@ -74,6 +74,18 @@ class GatheredPairs:
         return self.rowptr[rp0 + l1:rp0 + l1 + l2], self.col[e0 + nnz:e0 + 2 * nnz], self.val[e0 + nnz:e0 + 2 * nnz]
 
 
+    def forward_arrays(self):
+        """(nnz, rowptr, col, val) of all pairs in row-major order -- the arguments of Context.set_mp, i.e. how a rank
+        takes the gathered shards back into its context for the consistency transforms and the progressive phase."""
+        nnz, rps, cols, vals = [], [], [], []
+        for x in range(self.n):
+            for y in range(x + 1, self.n):
+                rp, col, val = self.csr(x, y)
+                nnz.append(len(col)); rps.append(rp); cols.append(col); vals.append(val)
+        return (np.array(nnz, np.uint32), np.concatenate(rps).astype(np.uint32), np.concatenate(cols).astype(np.uint32),
+                np.concatenate(vals).astype(np.float32))
+
+
 class ShardExchange:
     """Pre-sized slabs for the all-gather of one shard's outputs (sizes exchanged once up front)."""
 

@@ -82,6 +82,15 @@ def _worker(rank, world, port, q):
         assert seen == total
         sm = g.sim_matrix()
         assert np.array_equal(sm, sm.T) and np.all(np.diag(sm) == 1)
+        # the hand-over to Context.set_mp: every pair's forward rows, row-major pair order
+        fn, frp, fc, fv = g.forward_arrays()
+        r0 = e0 = p = 0
+        for x in range(n):
+            for y in range(x + 1, n):
+                rp, c, v = orc.align_calculate(seqs[x], seqs[y], 0.01, 0)
+                assert fn[p] == len(c) and np.array_equal(frp[r0:r0 + lens[x] + 1], rp)
+                assert np.array_equal(fc[e0:e0 + len(c)], c) and fv[e0:e0 + len(c)].tobytes() == v.tobytes()
+                r0 += lens[x] + 1; e0 += len(c); p += 1
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback
