@@ -104,6 +104,7 @@ _make_brackets = _sig("dafs_hip_make_brackets", None, [C.c_uint32, C.c_void_p, C
 _dd_default_params = _sig("dafs_hip_dd_default_params", None, [C.POINTER(DDParams)])
 _solve_nodes = _sig("dafs_hip_solve_nodes", C.c_int,
                     [C.c_void_p, C.c_uint32, C.POINTER(NodeInput), C.POINTER(DDParams), C.POINTER(NodeOutput)])
+_build_tree = _sig("dafs_host_build_tree", C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
 _set_mp = _sig("dafs_hip_set_mp", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
 _nodes_open = _sig("dafs_hip_nodes_open", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(NodeInput), C.POINTER(DDParams), C.c_void_p])
 _nodes_advance = _sig("dafs_hip_nodes_advance", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(DDParams), C.c_uint32, C.c_void_p])
@@ -351,6 +352,15 @@ class Context:
         check(_consensus_structure(self._h, n, L, seq.ctypes.data, mask.ctypes.data, th, ss.ctypes.data, C.byref(score),
                                    None if p is None else p.ctypes.data))
         return np.float32(score.value), ss, p
+
+
+def build_tree(sim):
+    """DAFS::build_tree (host code in the library): (score, left, right) with -1 for leaves"""
+    sim = np.ascontiguousarray(sim, np.float32)
+    n = sim.shape[0]
+    score = np.zeros(2 * n - 1, np.float32); left = np.zeros(2 * n - 1, np.int32); right = np.zeros(2 * n - 1, np.int32)
+    check(_build_tree(n, sim.ctypes.data, score.ctypes.data, left.ctypes.data, right.ctypes.data))
+    return score, left.astype(np.int64), right.astype(np.int64)
 
 
 def dd_params(**kw):

@@ -180,35 +180,13 @@ Options parse(int argc, char** argv) {
 // ---------------------------------------------------------------------------------------------
 typedef std::pair<float, std::pair<uint, uint> > node_t;
 
-// DAFS::build_tree, reference src/dafs.cpp:446-492: greedy joins from a max-heap of similarities
+// DAFS::build_tree, reference src/dafs.cpp:446-492 (dafs_host_build_tree in the library; host code)
 std::vector<node_t> build_tree(const std::vector<float>& sim, uint n0) {
-  uint n = n0;
-  std::vector<node_t> tree(2 * n - 1, std::make_pair(0.0f, std::make_pair(-1u, -1u)));
-  VVF d(n, VF(n, 0.0f));
-  VU idx(2 * n - 1, -1u);
-  for (uint i = 0; i != n; ++i) idx[i] = i;
-  std::priority_queue<node_t> pq;
-  for (uint i = 0; i + 1 < n; ++i)
-    for (uint j = i + 1; j != n; ++j) {
-      d[i][j] = d[j][i] = sim[(size_t)i * n0 + j];
-      pq.push(std::make_pair(sim[(size_t)i * n0 + j], std::make_pair(i, j)));
-    }
-  while (!pq.empty()) {
-    const node_t t = pq.top();
-    pq.pop();
-    const uint a = t.second.first, b = t.second.second;
-    if (idx[a] == -1u || idx[b] == -1u) continue;
-    const uint l = idx[a], r = idx[b];
-    idx[a] = idx[b] = -1u;
-    for (uint i = 0; i != n; ++i)
-      if (idx[i] != -1u) {
-        const uint ii = idx[i];
-        d[ii][l] = d[l][ii] = (d[ii][l] + d[ii][r]) * t.first / 2;
-        pq.push(std::make_pair(d[ii][l], std::make_pair(i, n)));
-      }
-    tree[n] = t;
-    idx[n++] = l;
-  }
+  std::vector<float> score(2 * n0 - 1);
+  std::vector<int32_t> left(2 * n0 - 1), right(2 * n0 - 1);
+  check(dafs_host_build_tree(n0, sim.data(), score.data(), left.data(), right.data()));
+  std::vector<node_t> tree(2 * n0 - 1);
+  for (uint i = 0; i < 2 * n0 - 1; ++i) tree[i] = std::make_pair(score[i], std::make_pair((uint)left[i], (uint)right[i]));
   return tree;
 }
 

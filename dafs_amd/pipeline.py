@@ -108,7 +108,7 @@ def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25
     t.append(time.perf_counter())
     sim = ctx.sim()
     ctx.consistency(w_pct_a, w_pct_s)
-    score, left, right = build_tree(sim)
+    score, left, right = capi.build_tree(sim)  # same code as the command line (build_tree below is its Python twin, kept for the CPU tests)
     t.append(time.perf_counter())
     res = Result()
     res.sim = sim

@@ -205,6 +205,10 @@ int dafs_hip_fold_posteriors(dafs_hip_ctx* ctx, int model, float th);
 int dafs_hip_fold_posterior_dense(dafs_hip_ctx* ctx, const char* seq, uint32_t len, const char* constraint, float* post,
                                   float* logz);
 
+/* Host-side helper (no device work): DAFS::build_tree (src/dafs.cpp:446-492) on the N*N similarity matrix.
+ * score/left/right: 2N-1 entries; leaves have left = right = -1, node N+k is the k-th join of slots left, right. */
+int dafs_host_build_tree(uint32_t n, const float* sim, float* score, int32_t* left, int32_t* right);
+
 /* ------------------------------------------------------------------------------------------
  * L1: probabilistic consistency transforms.
  * Replaces DAFS::relax_basepairing_probability (src/dafs.cpp:326-375) and

@@ -67,3 +67,18 @@ def test_plan_covers_lengths():
         assert p.scratch_bytes == p.nwaves * p.slab_steps * p.width * 64 * 4
     assert capi.pairhmm_plan(1, 10, 5000, p) == -4
     assert capi.pairhmm_plan(0, 10, 10, p) == -1
+
+
+def test_host_build_tree_matches_python_twin():
+    """dafs_host_build_tree (host code inside the library, used by the CLI and the pipeline driver) against the
+    Python restatement of DAFS::build_tree, on random similarity matrices with ties."""
+    from dafs_amd import capi, pipeline
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 9, 33):
+        s = rng.integers(0, 50, size=(n, n)).astype(np.float32) / np.float32(64)
+        s = np.maximum(s, s.T)
+        np.fill_diagonal(s, 1.0)
+        a = capi.build_tree(s)
+        b = pipeline.build_tree(s)
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])

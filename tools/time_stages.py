@@ -14,9 +14,9 @@ for rep in range(2):
     ctx.fold_posteriors(0.01); t.append(time.perf_counter())
     ctx.align_posteriors(fetch=False); t.append(time.perf_counter())
     sim = ctx.sim(); ctx.consistency(0.25, 0.25); t.append(time.perf_counter())
-    tree = pipeline.build_tree(sim); t.append(time.perf_counter())
+    tree = capi.build_tree(sim); t.append(time.perf_counter())
     if rep:
-        print("set_seq %.1f ms | fold %.1f | pair(L1 call) %.1f | pct %.1f | tree(py) %.1f" % tuple(1e3 * (b - a) for a, b in zip(t, t[1:])))
+        print("set_seq %.1f ms | fold %.1f | pair(L1 call) %.1f | pct %.1f | tree %.1f" % tuple(1e3 * (b - a) for a, b in zip(t, t[1:])))
 res = pipeline.run(names, seqs, ctx=ctx, level_sync=os.environ.get("DAFS_LEVEL_SYNC") == "1", slice_iters=int(os.environ.get("DAFS_SLICE", "64")))
 print({k: round(v, 3) for k, v in res.seconds.items()}, "levels", res.levels, "cols", len(res.rows[0]))
 its = sorted(v[0] for v in res.dd_log.values())
