@@ -40,6 +40,7 @@ struct cf_ctx {  // per-workgroup view
   const int* pcnt;
   float* ring;           // LDS ring of the last 33 spans of FC (inside) / FCo (outside): ring[(span % 33)*(L+1) + row]; null = none
   const cf_params* P;    // score tables (LDS copy)
+  bool free;             // no constraint string: every map entry is -1 and cum is all zero, the lookups are skipped
 };
 #define CF_RING 33
 
@@ -49,12 +50,13 @@ __device__ __forceinline__ bool cf_comp(int a, int b) {  // AU, GU, CG (Inferenc
 // allow_paired[offset[i]+j] after LoadSequence (:947-1097) and UseConstraints (:1870-1902)
 __device__ __forceinline__ bool cf_allow_paired(const cf_ctx& c, int i, int j) {
   if (i <= 0 || j <= i || j > c.L) return false;
+  if (c.free) return cf_comp(c.s[i], c.s[j]);
   const int mi = c.map[i], mj = c.map[j];
   return (mi == -1 || mi == j) && (mj == -1 || mj == i) && cf_comp(c.s[i], c.s[j]);
 }
 // every position in (lo, hi] may be unpaired
-__device__ __forceinline__ bool cf_all_unpaired(const cf_ctx& c, int lo, int hi) { return c.cum[hi] - c.cum[lo] == 0; }
-__device__ __forceinline__ bool cf_unpaired_pos(const cf_ctx& c, int t) { return c.cum[t] - c.cum[t - 1] == 0; }
+__device__ __forceinline__ bool cf_all_unpaired(const cf_ctx& c, int lo, int hi) { return c.free || c.cum[hi] - c.cum[lo] == 0; }
+__device__ __forceinline__ bool cf_unpaired_pos(const cf_ctx& c, int t) { return c.free || c.cum[t] - c.cum[t - 1] == 0; }
 
 #define S_(i) (c.s[i])
 __device__ __forceinline__ float cf_junction_a(const cf_ctx& c, int i, int j) {  // :1927-1956
@@ -74,6 +76,7 @@ __device__ __forceinline__ float cf_hairpin(const cf_ctx& c, int i, int j) {  //
 }
 __device__ __forceinline__ float cf_single_nuc(const cf_ctx& c, int i, int j, int p, int q) {  // :2290-2361
   const int l1 = p - i, l2 = j - q;
+  if (l1 + l2 > 2 || (l1 | l2) > 1) return 0.0f;  // every addend below is the literal 0.0f then: the sum is +0.0f
   return 0.0f + 0.0f + (l1 == 0 && l2 == 1 ? c.P->bulge_0x1[S_(j)] : 0.0f) + (l1 == 1 && l2 == 0 ? c.P->bulge_1x0[S_(i + 1)] : 0.0f) +
          (l1 == 1 && l2 == 1 ? c.P->internal_1x1[S_(i + 1) * 5 + S_(j)] : 0.0f);
 }
@@ -85,6 +88,7 @@ __device__ __forceinline__ float cf_single_nuc(const cf_ctx& c, int i, int j, in
 // ---------------------------------------------------------------------------------------------
 // constraint part of allow_paired for a symbol-compatible pair (a < q)
 __device__ __forceinline__ bool cf_map_ok(const cf_ctx& c, int a, int q) {
+  if (c.free) return true;
   const int ma = c.map[a], mq = c.map[q];
   return (ma == -1 || ma == q) && (mq == -1 || mq == a);
 }
@@ -338,6 +342,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B, int use_r
   float* ring = use_ring ? (float*)(s_ints + CF_INTS(L)) : nullptr;
   cf_ctx c;
   cf_bind(c, L, s_ints, ring, &sP);
+  c.free = !sq.has_constraint;
   int* s = (int*)c.s; int* map = (int*)c.map; int* cum = (int*)c.cum; int* off = (int*)c.off;
   int* plist = (int*)c.plist; int* pcnt = (int*)c.pcnt;
   float* F = B.fws + sq.fws_off;
@@ -464,6 +469,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_contrafold_posterior(cf_batch B)
   __syncthreads();
   cf_ctx c;
   cf_bind(c, L, s_ints, nullptr, &sP);
+  c.free = !sq.has_constraint;
   float* F = B.fws + sq.fws_off;
   const size_t SZ = (size_t)(L + 1) * (L + 2) / 2;
   const float *FCi = F, *FCo = F + 3 * SZ, *FM1o = F + 5 * SZ, *F5i = F + 7 * SZ, *F5o = F5i + (L + 1);
