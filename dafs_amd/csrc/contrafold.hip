@@ -145,7 +145,7 @@ __device__ void cf_inside_cell(const cf_ctx& c, int i, int j, float* FCi, float*
     for (int p = i; p <= pmax; p++) {
       if (p > i && !cf_unpaired_pos(c, p)) break;
       const int q_min = max(p + 2, p - i + j - CF_MAX_SINGLE);
-      const int sy = c.s[p + 1];
+      const int sy = c.s[p + 1], sp = c.s[p];
       if (sy == 4) continue;  // a non-ACGU symbol pairs with nothing
       const int* pl = c.plist + sy * L;
       for (int e = c.pcnt[sy * (L + 2) + j] - 1; e >= 0; --e) {  // partners q of p+1, q = j downwards
@@ -154,10 +154,13 @@ __device__ void cf_inside_cell(const cf_ctx& c, int i, int j, float* FCi, float*
         if (q < j && !cf_all_unpaired(c, q, j)) break;
         if (!cf_map_ok(c, p + 1, q)) continue;
         const float inner = cf_fc_load(c, FCi, p + 1, q - 1);
+        // ScoreBasePair(p+1,q) and ScoreJunctionB(q,p) with the symbols of p and p+1 read once per p
+        const int sq_ = c.s[q], sq1 = c.s[q + 1];
+        const float bp = 0.0f + c.P->base_pair[sy * 5 + sq_];
+        const float jb = 0.0f + c.P->helix_closing[sq_ * 5 + sy] + c.P->terminal_mismatch[((sq_ * 5 + sy) * 5 + sq1) * 5 + sp];
         const float score = (p == i && q == j)
                                 ? (score_helix + inner)
-                                : (score_other + c.P->cache_single[(p - i) * 31 + (j - q)] + inner + cf_base_pair(c, p + 1, q) +
-                                   cf_junction_b(c, q, p) + cf_single_nuc(c, i, j, p, q));
+                                : (score_other + c.P->cache_single[(p - i) * 31 + (j - q)] + inner + bp + jb + cf_single_nuc(c, i, j, p, q));
         sum = contra_lpe(sum, score);
       }
     }
@@ -205,6 +208,7 @@ __device__ void cf_outside_cell(const cf_ctx& c, int a, int b, const float* FCi,
       const float temp = F5o[q] + c.P->external_paired + cf_base_pair(c, p + 1, q) + cf_junction_a(c, q, p);
       fco = contra_lpe(fco, temp + F5i[p]);
     }
+    const float bp_pq = cf_base_pair(c, p + 1, q), jb_qp = cf_junction_b(c, q, p);  // the same two addends in every single-branch term
     for (int i = max(1, p - CF_MAX_SINGLE); i <= p; i++) {
       const int l1 = p - i;
       if (l1 > 0 && !cf_all_unpaired(c, i, p)) continue;
@@ -223,8 +227,7 @@ __device__ void cf_outside_cell(const cf_ctx& c, int a, int b, const float* FCi,
           if (l2 > 0 && !cf_all_unpaired(c, q, j)) continue;
           const float src = cf_fc_load(c, FCo, i, j);
           const float score_other = src + cf_junction_b(c, i, j);
-          fco = contra_lpe(fco, score_other + c.P->cache_single[l1 * 31 + l2] + cf_base_pair(c, p + 1, q) + cf_junction_b(c, q, p) +
-                                    cf_single_nuc(c, i, j, p, q));
+          fco = contra_lpe(fco, score_other + c.P->cache_single[l1 * 31 + l2] + bp_pq + jb_qp + cf_single_nuc(c, i, j, p, q));
         }
       }
       if (i == p && q <= jmax) {
