@@ -142,6 +142,17 @@ __device__ __forceinline__ contra_f2 contra_lpe2_t(const contra_tables* t, contr
   return o;
 }
 
+// one Fast_LogPlusEquals through the tables
+__device__ __forceinline__ float contra_lpe_t(const contra_tables* t, float x, float y) {
+  const float hi = fmaxf(x, y), lo = fminf(x, y);
+  const float d = hi - lo;
+  const unsigned g = min((unsigned)(d * 2.0f), 23u);
+  const float2 cl = t->lcell[g];
+  const unsigned i = (unsigned)__float_as_int(cl.y) + (d >= cl.x ? 1u : 0u);
+  const float r = ((t->lk[0][i] * d + t->lk[1][i]) * d + t->lk[2][i]) * d + t->lk[3][i] + lo;
+  return (lo > (float)(-2e20 / 2) && d < (float)(11.8624794162)) ? r : hi;
+}
+
 // two Fast_Exp at once (LogSpace.hpp:28-60); arguments >= 0 take the scalar path (expf, see contra_exp)
 __device__ __forceinline__ contra_f2 contra_exp2_t(const contra_tables* t, contra_f2 x) {
   const contra_f2 s = (x + 10.0f) * 2.0f;

@@ -24,6 +24,14 @@
 
 namespace dafs {
 
+// Fast_LogPlusEquals of this file picks its cubic through an LDS table (contra_lpe_t): fewer instructions than the
+// select tree at the price of one more LDS round trip on the dependency chain -- the kernel is bound by the
+// instruction stream of the few wavefronts a sequence occupies (65 -> 58 ms at N=128).  Same values either way.
+__shared__ contra_tables g_cf_tab;
+__device__ __forceinline__ float cf_lpe(float x, float y) { return contra_lpe_t(&g_cf_tab, x, y); }
+#define CF_TABLES_INIT() do { contra_tables_init(&g_cf_tab, threadIdx.x); } while (0)
+
+
 #define CF_MAX_SINGLE 30  // C_MAX_SINGLE_LENGTH, Config.hpp:213
 #define CF_THREADS 256
 
@@ -112,17 +120,17 @@ __device__ __forceinline__ float cf_fold(float acc, int n, F term) {
 #pragma unroll
       for (int u = 0; u < CF_FOLD; ++u) { cur[u] = nx[u]; nx[u] = term(k + CF_FOLD + u); }
 #pragma unroll
-      for (int u = 0; u < CF_FOLD; ++u) acc = contra_lpe(acc, cur[u]);
+      for (int u = 0; u < CF_FOLD; ++u) acc = cf_lpe(acc, cur[u]);
     }
 #pragma unroll
-    for (int u = 0; u < CF_FOLD; ++u) acc = contra_lpe(acc, nx[u]);
+    for (int u = 0; u < CF_FOLD; ++u) acc = cf_lpe(acc, nx[u]);
     k += CF_FOLD;
   }
   for (; k + 4 <= n; k += 4) {
     const float a0 = term(k), a1 = term(k + 1), a2 = term(k + 2), a3 = term(k + 3);
-    acc = contra_lpe(contra_lpe(contra_lpe(contra_lpe(acc, a0), a1), a2), a3);
+    acc = cf_lpe(cf_lpe(cf_lpe(cf_lpe(acc, a0), a1), a2), a3);
   }
-  for (; k < n; ++k) acc = contra_lpe(acc, term(k));
+  for (; k < n; ++k) acc = cf_lpe(acc, term(k));
   return acc;
 }
 
@@ -138,7 +146,7 @@ __device__ void cf_inside_cell(const cf_ctx& c, int i, int j, float* FCi, float*
   const bool closing = (0 < i && j < L && cf_allow_paired(c, i, j + 1));
   if (closing) {
     float sum = CONTRA_NEG_INF;
-    if (cf_all_unpaired(c, i, j)) sum = contra_lpe(sum, cf_hairpin(c, i, j));
+    if (cf_all_unpaired(c, i, j)) sum = cf_lpe(sum, cf_hairpin(c, i, j));
     const float score_helix = (i + 2 <= j ? cf_base_pair(c, i + 1, j) + cf_helix_stacking(c, i, j + 1) : 0.0f);
     const float score_other = cf_junction_b(c, i, j);
     const int pmax = min(i + CF_MAX_SINGLE, j);
@@ -161,10 +169,10 @@ __device__ void cf_inside_cell(const cf_ctx& c, int i, int j, float* FCi, float*
         const float score = (p == i && q == j)
                                 ? (score_helix + inner)
                                 : (score_other + c.P->cache_single[(p - i) * 31 + (j - q)] + inner + bp + jb + cf_single_nuc(c, i, j, p, q));
-        sum = contra_lpe(sum, score);
+        sum = cf_lpe(sum, score);
       }
     }
-    sum = contra_lpe(sum, FM2i + cf_junction_a(c, i, j) + c.P->multi_paired + c.P->multi_base);
+    sum = cf_lpe(sum, FM2i + cf_junction_a(c, i, j) + c.P->multi_paired + c.P->multi_base);
     FCi[off[i] + j] = sum;
     fc = sum;
   }
@@ -172,13 +180,13 @@ __device__ void cf_inside_cell(const cf_ctx& c, int i, int j, float* FCi, float*
   if (0 < i && i + 2 <= j && j < L) {
     float sum = CONTRA_NEG_INF;
     if (cf_allow_paired(c, i + 1, j))
-      sum = contra_lpe(sum, cf_fc_load(c, FCi, i + 1, j - 1) + cf_junction_a(c, j, i) + c.P->multi_paired + cf_base_pair(c, i + 1, j));
-    if (cf_unpaired_pos(c, i + 1)) sum = contra_lpe(sum, FM1i[off[i + 1] + j] + MULTI_UNPAIRED);
+      sum = cf_lpe(sum, cf_fc_load(c, FCi, i + 1, j - 1) + cf_junction_a(c, j, i) + c.P->multi_paired + cf_base_pair(c, i + 1, j));
+    if (cf_unpaired_pos(c, i + 1)) sum = cf_lpe(sum, FM1i[off[i + 1] + j] + MULTI_UNPAIRED);
     FM1i[off[i] + j] = sum;
     float sm = CONTRA_NEG_INF;
-    sm = contra_lpe(sm, FM2i);
-    if (cf_unpaired_pos(c, j)) sm = contra_lpe(sm, FMi[off[i] + j - 1] + MULTI_UNPAIRED);
-    sm = contra_lpe(sm, sum);
+    sm = cf_lpe(sm, FM2i);
+    if (cf_unpaired_pos(c, j)) sm = cf_lpe(sm, FMi[off[i] + j - 1] + MULTI_UNPAIRED);
+    sm = cf_lpe(sm, sum);
     FMi[off[i] + j] = sm;
   }
 }
@@ -196,7 +204,7 @@ __device__ void cf_outside_cell(const cf_ctx& c, int a, int b, const float* FCi,
   if (a < b) {
     fmo = cf_fold(fmo, a, [&](int i) { return FM2o[off[i] + b] + FM1i[off[i] + a]; });
   }
-  if (0 < a && a + 2 <= b + 1 && b + 1 < L && cf_unpaired_pos(c, b + 1)) fmo = contra_lpe(fmo, FMo[off[a] + b + 1] + MULTI_UNPAIRED);
+  if (0 < a && a + 2 <= b + 1 && b + 1 < L && cf_unpaired_pos(c, b + 1)) fmo = cf_lpe(fmo, FMo[off[a] + b + 1] + MULTI_UNPAIRED);
   FMo[off[a] + b] = fmo;
 
   // ---- FCo[a][b] (only cells whose closing pair (a, b+1) is allowed ever receive anything)
@@ -206,7 +214,7 @@ __device__ void cf_outside_cell(const cf_ctx& c, int a, int b, const float* FCi,
     const int p = a - 1, q = b + 1;
     {  // exterior loop, first sweep (:3754-3766): k = p, j = q
       const float temp = F5o[q] + c.P->external_paired + cf_base_pair(c, p + 1, q) + cf_junction_a(c, q, p);
-      fco = contra_lpe(fco, temp + F5i[p]);
+      fco = cf_lpe(fco, temp + F5i[p]);
     }
     const float bp_pq = cf_base_pair(c, p + 1, q), jb_qp = cf_junction_b(c, q, p);  // the same two addends in every single-branch term
     for (int i = max(1, p - CF_MAX_SINGLE); i <= p; i++) {
@@ -227,16 +235,16 @@ __device__ void cf_outside_cell(const cf_ctx& c, int a, int b, const float* FCi,
           if (l2 > 0 && !cf_all_unpaired(c, q, j)) continue;
           const float src = cf_fc_load(c, FCo, i, j);
           const float score_other = src + cf_junction_b(c, i, j);
-          fco = contra_lpe(fco, score_other + c.P->cache_single[l1 * 31 + l2] + bp_pq + jb_qp + cf_single_nuc(c, i, j, p, q));
+          fco = cf_lpe(fco, score_other + c.P->cache_single[l1 * 31 + l2] + bp_pq + jb_qp + cf_single_nuc(c, i, j, p, q));
         }
       }
       if (i == p && q <= jmax) {
         // source (p,q): block 2 (:3787-3789) comes before its own single-branch scatter (helix term)
         if (0 < p && p + 2 <= q && q < L)
-          fco = contra_lpe(fco, FM1o[off[p] + q] + cf_junction_a(c, q, p) + c.P->multi_paired + cf_base_pair(c, p + 1, q));
+          fco = cf_lpe(fco, FM1o[off[p] + q] + cf_junction_a(c, q, p) + c.P->multi_paired + cf_base_pair(c, p + 1, q));
         if (cf_allow_paired(c, p, q + 1)) {
           const float score_helix = cf_fc_load(c, FCo, p, q) + cf_base_pair(c, p + 1, q) + cf_helix_stacking(c, p, q + 1);
-          fco = contra_lpe(fco, score_helix);
+          fco = cf_lpe(fco, score_helix);
         }
       }
     }
@@ -246,18 +254,18 @@ __device__ void cf_outside_cell(const cf_ctx& c, int a, int b, const float* FCi,
 
   // ---- FM1o[a][b]: block 2 of source (a-1,b), block 4 of sources (a,j) j = L..b+1, block 1 of source (a,b)
   float fm1o = CONTRA_NEG_INF;
-  if (0 < a - 1 && a - 1 + 2 <= b && b < L && cf_unpaired_pos(c, a)) fm1o = contra_lpe(fm1o, FM1o[off[a - 1] + b] + MULTI_UNPAIRED);
+  if (0 < a - 1 && a - 1 + 2 <= b && b < L && cf_unpaired_pos(c, a)) fm1o = cf_lpe(fm1o, FM1o[off[a - 1] + b] + MULTI_UNPAIRED);
   if (a < b) {
     fm1o = cf_fold(fm1o, L - b, [&](int u) { const int j = L - u; return FM2o[off[a] + j] + FMi[off[b] + j]; });
   }
   const bool live = (0 < a && a + 2 <= b && b < L);
-  if (live) fm1o = contra_lpe(fm1o, fmo);
+  if (live) fm1o = cf_lpe(fm1o, fmo);
   FM1o[off[a] + b] = fm1o;
 
   // ---- FM2o(a,b), the value the reference holds locally while scattering from (a,b)
   float fm2o = CONTRA_NEG_INF;
-  if (live) fm2o = contra_lpe(fm2o, fmo);
-  if (pair_ok) fm2o = contra_lpe(fm2o, fco + cf_junction_a(c, a, b) + c.P->multi_paired + c.P->multi_base);
+  if (live) fm2o = cf_lpe(fm2o, fmo);
+  if (pair_ok) fm2o = cf_lpe(fm2o, fco + cf_junction_a(c, a, b) + c.P->multi_paired + c.P->multi_base);
   FM2o[off[a] + b] = fm2o;
 }
 
@@ -330,6 +338,7 @@ __device__ void cf_bind(cf_ctx& c, int L, int* ints, float* ring, const cf_param
 }
 
 __global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B, int use_ring) {
+  CF_TABLES_INIT();
   __shared__ cf_params sP;
   __shared__ float s_terms[CF_THREADS];
   {
@@ -412,11 +421,11 @@ __global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B, int use_r
       __syncthreads();
       if (tid == 0) {
         float sum = (k0 == 0) ? CONTRA_NEG_INF : F5i[j];
-        if (k0 == 0 && cf_unpaired_pos(c, j)) sum = contra_lpe(sum, F5i[j - 1] + EXT_UNPAIRED);
+        if (k0 == 0 && cf_unpaired_pos(c, j)) sum = cf_lpe(sum, F5i[j - 1] + EXT_UNPAIRED);
         const int n = min(nt, j - k0);
         for (int u = 0; u < n; ++u) {
           const float v = s_terms[u];
-          if (v == v) sum = contra_lpe(sum, v);
+          if (v == v) sum = cf_lpe(sum, v);
         }
         F5i[j] = sum;
       }
@@ -436,10 +445,10 @@ __global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B, int use_r
     const float f5oj = F5o[j];
     for (int k = tid; k < j; k += nt) {
       float v = F5o[k];
-      if (k == j - 1 && cf_unpaired_pos(c, j)) v = contra_lpe(v, f5oj + EXT_UNPAIRED);
+      if (k == j - 1 && cf_unpaired_pos(c, j)) v = cf_lpe(v, f5oj + EXT_UNPAIRED);
       if (cf_allow_paired(c, k + 1, j)) {
         const float temp = f5oj + sP.external_paired + cf_base_pair(c, k + 1, j) + cf_junction_a(c, j, k);
-        v = contra_lpe(v, temp + FCi[off[k + 1] + j - 1]);
+        v = cf_lpe(v, temp + FCi[off[k + 1] + j - 1]);
       }
       F5o[k] = v;
     }
