@@ -129,6 +129,8 @@ extern "C" int dafs_hip_create(int device, dafs_hip_ctx** out) {
   dafs_hip_ctx* c = new dafs_hip_ctx();
   c->device = device;
   if (hip_check(hipStreamCreate(&c->stream))) { delete c; return DAFS_HIP_ENODEV; }
+  int cus = 0;
+  if (!hip_check(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) && cus > 0) c->num_cus = cus;
   *out = c;
   return DAFS_HIP_OK;
 }

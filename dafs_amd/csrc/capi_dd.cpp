@@ -337,7 +337,8 @@ int nodes_advance(dafs_hip_ctx* c, uint32_t n, const uint32_t* handles, dd_param
   const char* split_env = getenv("DAFS_HIP_DD_SPLIT");
   const bool split_allowed = !(split_env && atoi(split_env) == 0);
   bool split = false;
-  if (split_allowed && nodes.size() * 3 <= 240)
+  // three workgroups per node, one per CU (their LDS does not leave room for a second): all of them must fit the device
+  if (split_allowed && (int)(nodes.size() * 3) <= c->num_cus - 16)
     for (size_t b = 0; b < nodes.size(); ++b) split = split || c->dd_open[handles[who[b]]].split_lds != 0;
   for (size_t b = 0; b < nodes.size(); ++b) {
     const dafs_hip_ctx::dd_open_node& on = c->dd_open[handles[who[b]]];

@@ -87,6 +87,7 @@ struct bp_store {
 
 struct dafs_hip_ctx {
   int device = 0;
+  int num_cus = 256;  // compute units of the device (co-residency bound of the split node solver)
   hipStream_t stream = nullptr;
   // sequences
   std::string seq;
