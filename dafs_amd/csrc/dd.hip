@@ -110,15 +110,20 @@ __device__ void nw_envelope(uint32_t L1, uint32_t L2, const float* __restrict__ 
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const bool in_lds = L1 <= 1024;
   if (in_lds) { fa = s_fl; la = s_fl + 1025; }
-  for (uint32_t i = tid + 1; i <= L1; i += nt) {
-    uint32_t f = 0, l = 0;
-    for (uint32_t k = 1; k <= L2; ++k)
-      if (p[(size_t)(i - 1) * L2 + (k - 1)] - th >= 0.0f) { f = k; break; }
-    if (f)
-      for (uint32_t k = L2; k != 0; --k)
-        if (p[(size_t)(i - 1) * L2 + (k - 1)] - th >= 0.0f) { l = k; break; }
-    fa[i] = f;
-    la[i] = l;
+  {  // a wavefront per row: one pass over the row, first and last column with p - th >= 0 from the ballots
+    const uint32_t wave = tid >> 6, lane = tid & 63, nwaves = nt >> 6;
+    for (uint32_t i = wave + 1; i <= L1; i += nwaves) {
+      uint32_t f = 0, l = 0;
+      for (uint32_t k0 = 0; k0 < L2; k0 += 64) {
+        const uint32_t k = k0 + lane;  // column k+1 of the reference's 1-based walk
+        const unsigned long long m = __ballot(k < L2 && p[(size_t)(i - 1) * L2 + k] - th >= 0.0f);
+        if (m) {
+          if (!f) f = k0 + (uint32_t)__ffsll((long long)m);
+          l = k0 + 64 - (uint32_t)__clzll((long long)m);
+        }
+      }
+      if (lane == 0) { fa[i] = f; la[i] = l; }
+    }
   }
   __syncthreads();
   uint32_t* ev = in_lds ? s_env : env;
@@ -870,26 +875,48 @@ __device__ void block_scan_inclusive(uint32_t* a, uint32_t n) {
   __syncthreads();
 }
 
+// sorted column lists of the entries > CUTOFF of every row (upper: only j > i).  A wavefront per row, the lanes
+// across the columns (coalesced reads), positions by ballot
 __device__ void row_lists(uint32_t R, uint32_t Cn, const float* P, bool upper, uint32_t* ptr, uint32_t* lst, int32_t* map) {
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
-  for (uint32_t i = tid; i < R; i += nt) {
+  const uint32_t wave = tid >> 6, lane = tid & 63, nwaves = nt >> 6;
+  for (uint32_t i = wave; i < R; i += nwaves) {
     uint32_t c = 0;
-    for (uint32_t j = upper ? i + 1 : 0; j < Cn; ++j) c += P[(size_t)i * Cn + j] > DD_CUTOFF ? 1 : 0;
-    ptr[i + 1] = c;
+    for (uint32_t j0 = upper ? ((i + 1) & ~63u) : 0; j0 < Cn; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      const bool keep = j < Cn && (!upper || j > i) && P[(size_t)i * Cn + j] > DD_CUTOFF;
+      c += (uint32_t)__popcll(__ballot(keep));
+    }
+    if (lane == 0) ptr[i + 1] = c;
   }
   if (tid == 0) ptr[0] = 0;
   __syncthreads();
   block_scan_inclusive(ptr + 1, R);
-  for (uint32_t i = tid; i < R; i += nt) {
+  for (uint32_t i = wave; i < R; i += nwaves) {
     uint32_t pos = ptr[i];
-    for (uint32_t j = upper ? i + 1 : 0; j < Cn; ++j)
-      if (P[(size_t)i * Cn + j] > DD_CUTOFF) {
-        lst[pos] = j;
-        if (map) map[(size_t)i * Cn + j] = (int32_t)pos;
-        ++pos;
+    for (uint32_t j0 = upper ? ((i + 1) & ~63u) : 0; j0 < Cn; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      const bool keep = j < Cn && (!upper || j > i) && P[(size_t)i * Cn + j] > DD_CUTOFF;
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const uint32_t q = pos + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        lst[q] = j;
+        if (map) map[(size_t)i * Cn + j] = (int32_t)q;
       }
+      pos += (uint32_t)__popcll(m);
+    }
   }
   __syncthreads();
+}
+
+// row of entry e: the largest i with ptr[i] <= e (ptr = exclusive row pointers, here an LDS copy)
+__device__ __forceinline__ uint32_t row_of_entry(const uint32_t* ptr, uint32_t R, uint32_t e) {
+  uint32_t lo = 0, hi = R;  // invariant: ptr[lo] <= e < ptr[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (ptr[mid] <= e) lo = mid; else hi = mid;
+  }
+  return lo;
 }
 
 __global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes, dd_params prm) {
@@ -904,8 +931,13 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes,
   if (tid == 0) s_total = 0;
   __syncthreads();
   uint32_t mine = 0;
-  for (uint32_t i = tid; i < L1; i += nt)  // a thread per row of p_x: the rows hold a handful of entries each
-    for (uint32_t e = nd.px_ptr[i]; e < nd.px_ptr[i + 1]; ++e) {
+  __shared__ uint32_t s_pxptr[DD_LMAX + 4];
+  for (uint32_t i = tid; i <= L1; i += nt) s_pxptr[i] = nd.px_ptr[i];
+  __syncthreads();
+  const uint32_t npx = s_pxptr[L1];
+  for (uint32_t e = tid; e < npx; e += nt) {  // a thread per entry of p_x
+    {
+      const uint32_t i = row_of_entry(s_pxptr, L1, e);
       const uint32_t j = nd.px_j[e];
       const float px = nd.p_x[(size_t)i * L1 + j];
       uint32_t c = 0;
@@ -921,6 +953,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes,
       nd.cbp_cnt[e] = c;
       mine += c;
     }
+  }
   atomicAdd(&s_total, mine);
   // alignment envelope + table initialisation
   nw_envelope(L1, L2, nd.p_z, prm.th_a, nd.env, nd.x, nd.z);  // x / z double as scratch here
@@ -937,8 +970,12 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_cbp_fill(const dd_node* nod
   // prefix of the per-entry counts (entries are already in (i,j) order); entry e starts at incl[e] - count[e],
   // i.e. at incl[e-1]
   block_scan_inclusive(nd.cbp_cnt, npx);
-  for (uint32_t i = tid; i < L1; i += nt)
-    for (uint32_t e = nd.px_ptr[i]; e < nd.px_ptr[i + 1]; ++e) {
+  __shared__ uint32_t s_pxptr[DD_LMAX + 4];
+  for (uint32_t i = tid; i <= L1; i += nt) s_pxptr[i] = nd.px_ptr[i];
+  __syncthreads();
+  for (uint32_t e = tid; e < npx; e += nt) {  // a thread per entry of p_x
+    {
+      const uint32_t i = row_of_entry(s_pxptr, L1, e);
       const uint32_t j = nd.px_j[e];
       const float px = nd.p_x[(size_t)i * L1 + j];
       uint32_t u = e ? nd.cbp_cnt[e - 1] : 0u;
@@ -963,20 +1000,34 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_cbp_fill(const dd_node* nod
       }
       nd.cx_flag[e] = u > u0 ? 1 : 0;                // c_x (:1038)
     }
+  }
   __syncthreads();
   // c_z as sorted row lists (:1056-1060) + dense id map
-  for (uint32_t i = tid; i < L1; i += nt) {
+  const uint32_t wave = tid >> 6, lane = tid & 63, nwaves = nt >> 6;
+  for (uint32_t i = wave; i < L1; i += nwaves) {
     uint32_t c = 0;
-    for (uint32_t k = 0; k < L2; ++k) c += nd.cz_flag[(size_t)i * L2 + k];
-    nd.cz_ptr[i + 1] = c;
+    for (uint32_t k0 = 0; k0 < L2; k0 += 64) {
+      const uint32_t k = k0 + lane;
+      c += (uint32_t)__popcll(__ballot(k < L2 && nd.cz_flag[(size_t)i * L2 + k] != 0));
+    }
+    if (lane == 0) nd.cz_ptr[i + 1] = c;
   }
   if (tid == 0) nd.cz_ptr[0] = 0;
   __syncthreads();
   block_scan_inclusive(nd.cz_ptr + 1, L1);
-  for (uint32_t i = tid; i < L1; i += nt) {
+  for (uint32_t i = wave; i < L1; i += nwaves) {
     uint32_t pos = nd.cz_ptr[i];
-    for (uint32_t k = 0; k < L2; ++k)
-      if (nd.cz_flag[(size_t)i * L2 + k]) { nd.cz_k[pos] = k; nd.zmap[(size_t)i * L2 + k] = (int32_t)pos; ++pos; }
+    for (uint32_t k0 = 0; k0 < L2; k0 += 64) {
+      const uint32_t k = k0 + lane;
+      const bool keep = k < L2 && nd.cz_flag[(size_t)i * L2 + k] != 0;
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const uint32_t q = pos + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        nd.cz_k[q] = k;
+        nd.zmap[(size_t)i * L2 + k] = (int32_t)q;
+      }
+      pos += (uint32_t)__popcll(m);
+    }
   }
   __syncthreads();
   const uint32_t ncbp = nd.info[0] < nd.ncbp_cap ? nd.info[0] : nd.ncbp_cap;
