@@ -105,12 +105,15 @@ class ShardExchange:
 
     def exchange(self, pair_nnz, sim, pair_off, rowptr, col, val, pool_used):
         """pair_nnz int32[n], sim float32[n], pair_off int64[n], rowptr int32[rp_total], col int32[cap],
-        val float32[cap] (all on self.device); pool_used = entries this rank produced.
-        One max-reduce for the payload stride, then the gather itself."""
+        val float32[cap] (all on self.device); pool_used = entries this rank produced (None: as in the previous
+        call).  One max-reduce for the payload stride, then the gather itself."""
         torch, dist = self.torch, self.dist
-        mx = torch.tensor([int(pool_used)], dtype=torch.int64, device=self.device)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        self.s_pool = int(mx.item())
+        if pool_used is not None or self.s_pool == 0:
+            mx = torch.tensor([int(pool_used)], dtype=torch.int64, device=self.device)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            self.s_pool = int(mx.item())
+        # pool_used=None: a repeat of an exchange whose sizes are known (same inputs): the stride agreed then is
+        # reused and nothing in this call waits for the device
         m = self.send_meta.view(self.s_pairs, 4)
         m[:self.n_pairs, 0] = pair_nnz
         m[:self.n_pairs, 1] = sim.view(torch.int32)
