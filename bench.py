@@ -103,9 +103,13 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("DAFS_BENCH_FORCE_EXCHANGE") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if world == 1:
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n_seq = args.n_seq or int(round(BASE_N * math.sqrt(world)))
     names, seqs, lens, px, py, total_pairs = build_shard(n_seq, args.length, world, rank)
@@ -127,53 +131,80 @@ def main():
     d_tasks = torch.from_numpy(tasks.view(np.int32)).to(dev)
     d_rp_off = torch.from_numpy(rp_off.view(np.int64)).to(dev)
     d_scratch = torch.empty(plan.scratch_bytes // 4, dtype=torch.float32, device=dev)
-    d_counters = torch.zeros(4, dtype=torch.int64, device=dev)  # [pool_top, queue, status, -]
-    d_rowptr = torch.empty(rp_total, dtype=torch.int32, device=dev)
-    d_col = torch.empty(pool_cap, dtype=torch.int32, device=dev)
-    d_val = torch.empty(pool_cap, dtype=torch.float32, device=dev)
-    d_pair_off = torch.empty(np_local, dtype=torch.int64, device=dev)
-    d_pair_nnz = torch.empty(np_local, dtype=torch.int32, device=dev)
-    d_sim = torch.empty(np_local, dtype=torch.float32, device=dev)
-
-    a = capi.Pairhmm3Args()
-    a.codes = d_codes.data_ptr(); a.tasks = d_tasks.data_ptr(); a.ntasks = np_local; a.th = args.th
-    a.scratch = d_scratch.data_ptr()
-    a.pool_top = d_counters.data_ptr(); a.queue = d_counters.data_ptr() + 8; a.status = d_counters.data_ptr() + 16
-    a.rp_off = d_rp_off.data_ptr(); a.rowptr_pool = d_rowptr.data_ptr()
-    a.ent_col = d_col.data_ptr(); a.ent_val = d_val.data_ptr(); a.pool_cap = pool_cap
-    a.pair_off = d_pair_off.data_ptr(); a.pair_nnz = d_pair_nnz.data_ptr(); a.sim = d_sim.data_ptr()
-    capi.pairhmm3_default_model(C.byref(a.model))
+    # Output buffers come in two sets: with several ranks the all-gather of step k runs on its own stream while the
+    # kernel of step k+1 fills the other set.
+    force_ex = os.environ.get("DAFS_BENCH_FORCE_EXCHANGE") == "1"  # exercise the exchange path on one rank (tests)
+    nsets = 2 if (world > 1 or force_ex) else 1
+    sets = []
+    for _ in range(nsets):
+        o = {"counters": torch.zeros(4, dtype=torch.int64, device=dev),  # [pool_top, queue, status, -]
+             "rowptr": torch.empty(rp_total, dtype=torch.int32, device=dev),
+             "col": torch.empty(pool_cap, dtype=torch.int32, device=dev),
+             "val": torch.empty(pool_cap, dtype=torch.float32, device=dev),
+             "pair_off": torch.empty(np_local, dtype=torch.int64, device=dev),
+             "pair_nnz": torch.empty(np_local, dtype=torch.int32, device=dev),
+             "sim": torch.empty(np_local, dtype=torch.float32, device=dev)}
+        a = capi.Pairhmm3Args()
+        a.codes = d_codes.data_ptr(); a.tasks = d_tasks.data_ptr(); a.ntasks = np_local; a.th = args.th
+        a.scratch = d_scratch.data_ptr()
+        a.pool_top = o["counters"].data_ptr(); a.queue = o["counters"].data_ptr() + 8; a.status = o["counters"].data_ptr() + 16
+        a.rp_off = d_rp_off.data_ptr(); a.rowptr_pool = o["rowptr"].data_ptr()
+        a.ent_col = o["col"].data_ptr(); a.ent_val = o["val"].data_ptr(); a.pool_cap = pool_cap
+        a.pair_off = o["pair_off"].data_ptr(); a.pair_nnz = o["pair_nnz"].data_ptr(); a.sim = o["sim"].data_ptr()
+        capi.pairhmm3_default_model(C.byref(a.model))
+        o["args"] = a
+        o["gathered"] = None  # event: the exchange that read this set has finished
+        sets.append(o)
+    d_counters = sets[0]["counters"]
 
     stream = torch.cuda.current_stream()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
     ex = None
-    if world > 1:
+    comm = None
+    if world > 1 or force_ex:
         from dafs_amd import dist as ddist
         ex = ddist.ShardExchange(dist, dev, world, np_local, rp_total, pool_cap)
-
+        comm = torch.cuda.Stream(device=dev)
     sized = [False]
+    nstep = [0]
 
     def step(k=None):
-        d_counters.zero_()
+        o = sets[nstep[0] % nsets]
+        nstep[0] += 1
+        if o["gathered"] is not None:
+            stream.wait_event(o["gathered"])  # this set is still being sent
+        o["counters"].zero_()
         if k is not None:
             ev0[k].record(stream)
-        capi.check(capi.pairhmm3_launch(C.byref(a), C.byref(plan), C.c_void_p(stream.cuda_stream)))
+        capi.check(capi.pairhmm3_launch(C.byref(o["args"]), C.byref(plan), C.c_void_p(stream.cuda_stream)))
         if k is not None:
             ev1[k].record(stream)
         if ex is not None:
-            # the one exchange of the path: every rank ends up with every pair's sparse posteriors
-            # payload size: read back once (host sync); the inputs do not change between steps, so later steps
-            # reuse the agreed stride and enqueue the gather without waiting for the device
+            # the one exchange of the path: every rank ends up with every pair's sparse posteriors.  Payload size:
+            # read back once (host sync); the inputs do not change between steps, so later steps reuse the agreed
+            # stride.  The gather runs on the communication stream, behind this step's kernel.
             used = None
             if not sized[0]:
-                used = int(d_counters[0].item())
+                used = int(o["counters"][0].item())
                 sized[0] = True
-            ex.exchange(d_pair_nnz, d_sim, d_pair_off, d_rowptr, d_col, d_val, used)
+            produced = torch.cuda.Event()
+            produced.record(stream)
+            comm.wait_event(produced)
+            with torch.cuda.stream(comm):
+                ex.exchange(o["pair_nnz"], o["sim"], o["pair_off"], o["rowptr"], o["col"], o["val"], used)
+                done = torch.cuda.Event()
+                done.record(comm)
+            o["gathered"] = done
+
+    def drain():
+        if comm is not None:
+            stream.wait_stream(comm)
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if int(d_counters[2].item()) != 0:
         raise SystemExit("pair-HMM kernel reported status %d" % int(d_counters[2].item()))
@@ -184,6 +215,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+    drain()  # the last exchange belongs to the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -254,7 +286,7 @@ def main():
         if e2e is not None:
             out["end_to_end"] = e2e
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
