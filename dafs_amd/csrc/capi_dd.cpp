@@ -373,12 +373,19 @@ int nodes_result(dafs_hip_ctx* c, uint32_t handle, dafs_node_output* out, bool s
   const dd_node& nd = c->dd_open[handle].nd;
   uint32_t info[16];
   float score = 0.0f;
-  auto down = [&](void* dst, const void* src, size_t bytes) {
-    return !dst || !hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-  };
-  bool ok = down(out->x, nd.x, (size_t)nd.L1 * 4) && down(out->y, nd.y, (size_t)nd.L2 * 4) && down(out->z, nd.z, (size_t)nd.L1 * 4) &&
-            down(&score, nd.score, 4) && down(info, nd.info, sizeof info);
-  if (!ok || hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
+  // x, y, z, score and info were carved back to back (nodes_open): one copy brings them all
+  const uint8_t* lo = (const uint8_t*)nd.x;
+  const uint8_t* hi = (const uint8_t*)(nd.info + 16);
+  if (hi <= lo || (size_t)(hi - lo) > ((size_t)2 * nd.L1 + nd.L2 + 64) * 4 + 8 * 256) return DAFS_HIP_EINVAL;
+  std::vector<uint8_t> blob((size_t)(hi - lo));
+  if (hip_check(hipMemcpyAsync(blob.data(), lo, blob.size(), hipMemcpyDeviceToHost, c->stream)) || hip_check(hipStreamSynchronize(c->stream)))
+    return DAFS_HIP_ELAUNCH;
+  auto at = [&](const void* dev_ptr) { return blob.data() + ((const uint8_t*)dev_ptr - lo); };
+  if (out->x) memcpy(out->x, at(nd.x), (size_t)nd.L1 * 4);
+  if (out->y) memcpy(out->y, at(nd.y), (size_t)nd.L2 * 4);
+  if (out->z) memcpy(out->z, at(nd.z), (size_t)nd.L1 * 4);
+  memcpy(&score, at(nd.score), 4);
+  memcpy(info, at(nd.info), sizeof info);
   if (stamps)
     fprintf(stderr, "dd node L1=%u L2=%u n=%u+%u ncbp=%u iters=%u slow-xy=%u+%u | us: x-dp %.0f x-traceback %.0f wait %.0f cbp %.0f update %.0f tail %.0f\n", nd.L1,
             nd.L2, nd.n1, nd.n2, info[0], info[1], info[4], info[5], info[8] / 100.0, info[9] / 100.0, info[10] / 100.0, info[11] / 100.0, info[12] / 100.0,
