@@ -451,33 +451,52 @@ __device__ __noinline__ float nuss_wave_fast(uint32_t W, uint32_t L, const float
 }
 
 // traceback of nuss_wave_reg's codes (see nuss_traceback_b for the walk)
-__device__ void nuss_traceback_fast(uint32_t L, uint32_t* trb_, uint32_t* lck_, uint32_t* ss_, uint32_t* stack_) {
+// Traceback of nuss_wave_reg's codes by the whole wavefront.  The walk itself is sequential, but it consists
+// of runs: stretches of code 1 (i+1), of code 2 (j-1) and stacks of code 3 (i+1, j-1).  The lanes read the
+// next 64 cells along the current direction at once and a ballot finds where the run ends, so a run costs
+// two LDS round trips instead of two per cell.  Bifurcations park their left half on an LDS stack.
+__device__ void nuss_traceback_fast(uint32_t L, uint32_t* trb_, uint32_t* lck_, uint32_t* ss_, uint32_t* stack_, int lane) {
   DD_LDS const uint32_t* trb = (DD_LDS const uint32_t*)trb_;
   DD_LDS const uint32_t* lck = (DD_LDS const uint32_t*)lck_;
   DD_LDS uint32_t* stack = (DD_LDS uint32_t*)stack_;
   DD_GLB uint32_t* ss = (DD_GLB uint32_t*)ss_;
+  auto code = [&](int i, int j) -> uint32_t {  // traceback code of cell (i, j), 0 outside the triangle j > i
+    if (!(i >= 0 && j > i && j < (int)L)) return 0u;
+    const uint32_t q = (uint32_t)tri_index(L, (uint32_t)i, (uint32_t)j);
+    return (trb[q >> 3] >> ((q & 7u) * 4)) & 15u;
+  };
   uint32_t sp = 0;
   int i = 0, j = (int)L - 1;
   uint32_t guard = 4 * L + 8;
   while (guard--) {
-    uint32_t t = 0;
-    if (j > i) {
-      const uint32_t q = (uint32_t)tri_index(L, (uint32_t)i, (uint32_t)j);
-      t = (trb[q >> 3] >> ((q & 7u) * 4)) & 15u;
-    }
+    const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)code(i, j));
     if (t == 0) {
       if (!sp) break;
-      const uint32_t e = stack[--sp];
+      --sp;
+      const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)stack[sp]);
       i = (int)(e >> 16); j = (int)(e & 0xFFFFu);
       continue;
     }
-    if (t == 1) ++i;
-    else if (t == 2) --j;
-    else if (t == 3) { ss[i] = j; ++i; --j; }
-    else {
-      const int k = (int)lck[(t - 4) * L + j];
-      ss[k] = j;
-      if (k - 1 > i) stack[sp++] = ((uint32_t)i << 16) | (uint32_t)(k - 1);
+    if (t == 1) {         // run of i+1: land on the first cell below whose code is not 1
+      const unsigned long long m = __ballot(code(i + 1 + lane, j) != 1u);
+      i += 1 + (m ? (int)__ffsll((long long)m) - 1 : 64);
+    } else if (t == 2) {  // run of j-1
+      const unsigned long long m = __ballot(code(i, j - 1 - lane) != 2u);
+      j -= 1 + (m ? (int)__ffsll((long long)m) - 1 : 64);
+    } else if (t == 3) {  // stack: (i, j) pairs, and so does every further cell (i+1+l, j-1-l) whose code is 3
+      const unsigned long long m = __ballot(code(i + 1 + lane, j - 1 - lane) != 3u);
+      const int r = m ? (int)__ffsll((long long)m) - 1 : 64;
+      if (lane == 0) ss[i] = (uint32_t)j;
+      if (lane < r) ss[i + 1 + lane] = (uint32_t)(j - 1 - lane);
+      i += 1 + r; j -= 1 + r;
+    } else {
+      const int k = (int)__builtin_amdgcn_readfirstlane((int)lck[(t - 4) * L + (uint32_t)j]);
+      if (lane == 0) {
+        ss[k] = (uint32_t)j;
+        if (k - 1 > i) stack[sp] = ((uint32_t)i << 16) | (uint32_t)(k - 1);
+      }
+      if (k - 1 > i) ++sp;
+      wave_lds_fence();
       i = k + 1; --j;
     }
   }
@@ -1086,11 +1105,9 @@ __device__ __noinline__ void dd_folder(const dd_node& nd, const dd_params& prm, 
       float sc = 0.0f;
       if (trbp && W <= DD_WREG) sc = nuss_wave_fast(W, L, S, trbp, ring, lck, lane, &slow);
       if (slow) sc = nuss_wave(L, S, ws, trb_g, trk, P, Sb, cc, lane);
-      if (lane == 0) {
-        s_fscore = sc;
-        if (slow) nuss_traceback_b(L, trb_g, trk, ss, (uint32_t*)P);
-        else nuss_traceback_fast(L, trbp, lck, ss, (uint32_t*)P);
-      }
+      if (lane == 0) s_fscore = sc;
+      if (!slow) nuss_traceback_fast(L, trbp, lck, ss, (uint32_t*)P, lane);
+      else if (lane == 0) nuss_traceback_b(L, trb_g, trk, ss, (uint32_t*)P);
     }
     __syncthreads();
     if (tid == 0) {
@@ -1206,11 +1223,9 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
       if (slow && lane == 0 && prm.stamps) nd.info[4] += 1;  // iterations that took the slower form
       if (slow) sc = nuss_wave(L1, nd.s_x, nd.wx, nd.trb_x, nd.trk_x, Px, Sbx, ccx, lane);
       DD_TICK(0);
-      if (lane == 0) {
-        s_score[0] = sc;
-        if (slow) nuss_traceback_b(L1, nd.trb_x, nd.trk_x, nd.x, (uint32_t*)Px);
-        else nuss_traceback_fast(L1, trxp, lckx, nd.x, (uint32_t*)Px);
-      }
+      if (lane == 0) s_score[0] = sc;
+      if (!slow) nuss_traceback_fast(L1, trxp, lckx, nd.x, (uint32_t*)Px, lane);
+      else if (lane == 0) nuss_traceback_b(L1, nd.trb_x, nd.trk_x, nd.x, (uint32_t*)Px);
       DD_TICK(1);
       if (shared_xy) {  // hand the region to the y folding
         wave_lds_fence();
@@ -1227,11 +1242,9 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
       if (tryp && Wy <= DD_WREG) sc = nuss_wave_fast(Wy, L2, nd.s_y, tryp, ringy, lcky, lane, &slow);
       if (slow && lane == 0 && prm.stamps) nd.info[5] += 1;
       if (slow) sc = nuss_wave(L2, nd.s_y, nd.wy, nd.trb_y, nd.trk_y, Py, Sby, ccy, lane);
-      if (lane == 0) {
-        s_score[1] = sc;
-        if (slow) nuss_traceback_b(L2, nd.trb_y, nd.trk_y, nd.y, (uint32_t*)Py);
-        else nuss_traceback_fast(L2, tryp, lcky, nd.y, (uint32_t*)Py);
-      }
+      if (lane == 0) s_score[1] = sc;
+      if (!slow) nuss_traceback_fast(L2, tryp, lcky, nd.y, (uint32_t*)Py, lane);
+      else if (lane == 0) nuss_traceback_b(L2, nd.trb_y, nd.trk_y, nd.y, (uint32_t*)Py);
     }
     if (wave == 2) {
       float sc;
