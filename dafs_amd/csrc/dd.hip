@@ -1281,10 +1281,12 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
     const uint32_t u0 = tid * chunk < ncbp ? tid * chunk : ncbp;
     const uint32_t u1 = u0 + chunk < ncbp ? u0 + chunk : ncbp;
     uint32_t npos = 0;
+    float sw_first = 0.0f;  // the value of this thread's first consensus pair (its only one when chunk == 1)
     for (uint32_t u = u0; u < u1; ++u) {
       const uint32_t* cb = nd.cbp + (size_t)8 * u;
       const float s_w = nd.q_x[(size_t)cb[0] * L1 + cb[1]] + nd.q_y[(size_t)cb[2] * L2 + cb[3]] -
                         nd.q_z[(size_t)cb[0] * L2 + cb[2]] - nd.q_z[(size_t)cb[1] * L2 + cb[3]];
+      if (u == u0) sw_first = s_w;
       if (s_w > 0.0f) {
         ++npos;
         atomicAdd(&nd.tx[cb[4]], 1);
@@ -1293,16 +1295,23 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
         atomicAdd(&nd.tz[cb[7]], 1);
       }
     }
-    s_cnt[tid] = npos;
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t run = 0;
-      for (uint32_t k = 0; k < nt; ++k) { const uint32_t v = s_cnt[k]; s_cnt[k] = run; run += v; }
-      s_npos = run;
+    // exclusive prefix of npos over the threads: a scan inside every wavefront, then the wavefront totals
+    uint32_t incl = npos;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o);
+      if ((int)(tid & 63) >= o) incl += up;
     }
+    if ((tid & 63) == 63) s_cnt[tid >> 6] = incl;
     __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t wv = 0; wv < (tid >> 6); ++wv) before += s_cnt[wv];
+    if (tid == nt - 1) s_npos = before + incl;
     {
-      uint32_t pos = s_cnt[tid];
+      uint32_t pos = before + incl - npos;
+      if (chunk == 1) {
+        if (npos) nd.sw[pos] = sw_first;
+      } else
       for (uint32_t u = u0; u < u1; ++u) {
         const uint32_t* cb = nd.cbp + (size_t)8 * u;
         const float s_w = nd.q_x[(size_t)cb[0] * L1 + cb[1]] + nd.q_y[(size_t)cb[2] * L2 + cb[3]] -
