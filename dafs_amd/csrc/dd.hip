@@ -1372,7 +1372,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
         }
       }
     }
-    for (uint32_t k = tid; k < L2; k += nt) {
+    for (uint32_t k = (tid + nt / 2) % nt; k < L2; k += nt) {  // the upper half of the workgroup starts on y while the lower half is on x
       const uint32_t l = nd.y[k];
       if (l != DD_NONE) {
         const int32_t id = nd.ymap[(size_t)k * L2 + l];
