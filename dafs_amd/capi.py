@@ -78,6 +78,10 @@ _fold_posteriors = _sig("dafs_hip_fold_posteriors", C.c_int, [C.c_void_p, C.c_in
 _fold_posterior_dense = _sig("dafs_hip_fold_posterior_dense", C.c_int,
                              [C.c_void_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_void_p, C.POINTER(C.c_float)])
 _consistency = _sig("dafs_hip_consistency", C.c_int, [C.c_void_p, C.c_float, C.c_float])
+_consistency_match = _sig("dafs_hip_consistency_match", C.c_int, [C.c_void_p, C.c_float])
+_consistency_bp = _sig("dafs_hip_consistency_bp", C.c_int, [C.c_void_p, C.c_float])
+_fold_begin = _sig("dafs_hip_fold_posteriors_begin", C.c_int, [C.c_void_p, C.c_int, C.c_float])
+_fold_end = _sig("dafs_hip_fold_posteriors_end", C.c_int, [C.c_void_p])
 
 
 class NodeInput(C.Structure):
@@ -242,6 +246,13 @@ class Context:
         """CONTRAfold base-pairing posteriors of every sequence -> the un-relaxed bp store"""
         check(_fold_posteriors(self._h, model, th))
 
+    def fold_begin(self, th=0.01, model=0):
+        """enqueue the folding kernels on their own stream; fold_end() waits and fills the bp store"""
+        check(_fold_begin(self._h, model, th))
+
+    def fold_end(self):
+        check(_fold_end(self._h))
+
     def fold_posterior_dense(self, seq, constraint=None):
         b = seq.encode() if isinstance(seq, str) else bytes(seq)
         L = len(b)
@@ -252,6 +263,12 @@ class Context:
 
     def consistency(self, w_pct_a=0.25, w_pct_s=0.25):
         check(_consistency(self._h, w_pct_a, w_pct_s))
+
+    def consistency_match(self, w_pct_a=0.25):
+        check(_consistency_match(self._h, w_pct_a))
+
+    def consistency_bp(self, w_pct_s=0.25):
+        check(_consistency_bp(self._h, w_pct_s))
 
     # --- decoder plugins ---
     def nussinov(self, p, q, th, w=0.0):

@@ -129,6 +129,8 @@ extern "C" int dafs_hip_create(int device, dafs_hip_ctx** out) {
   dafs_hip_ctx* c = new dafs_hip_ctx();
   c->device = device;
   if (hip_check(hipStreamCreate(&c->stream))) { delete c; return DAFS_HIP_ENODEV; }
+  // non-blocking: the folding must not be drawn into the implicit synchronisation of null-stream copies
+  if (hip_check(hipStreamCreateWithFlags(&c->fold_stream, hipStreamNonBlocking))) { (void)hipStreamDestroy(c->stream); delete c; return DAFS_HIP_ENODEV; }
   int cus = 0;
   if (!hip_check(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) && cus > 0) c->num_cus = cus;
   *out = c;
@@ -139,6 +141,7 @@ extern "C" void dafs_hip_destroy(dafs_hip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   c->free_all();
+  (void)hipStreamDestroy(c->fold_stream);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }

@@ -97,20 +97,20 @@ struct fold_job {
   }
 };
 
-int ensure_params(dafs_hip_ctx* c) {
+int ensure_params(dafs_hip_ctx* c, hipStream_t st) {
   if (c->cf_params_ready) return DAFS_HIP_OK;
   cf_params p;
   contrafold_default_params(&p);
-  int rc = c->d_cf_params.upload((const uint8_t*)&p, sizeof p, c->stream);
+  int rc = c->d_cf_params.upload((const uint8_t*)&p, sizeof p, st);
   if (rc) return rc;
   c->cf_params_ready = true;
   return DAFS_HIP_OK;
 }
 
-int run_job(dafs_hip_ctx* c, const fold_job& job, const uint8_t* d_codes, const int* d_cons, cf_batch* out) {
+int run_job(dafs_hip_ctx* c, const fold_job& job, const uint8_t* d_codes, const int* d_cons, cf_batch* out, hipStream_t st) {
   int rc;
-  if ((rc = ensure_params(c))) return rc;
-  if ((rc = c->cf_seqs.upload((const uint8_t*)job.seqs.data(), job.seqs.size() * sizeof(cf_seq), c->stream))) return rc;
+  if ((rc = ensure_params(c, st))) return rc;
+  if ((rc = c->cf_seqs.upload((const uint8_t*)job.seqs.data(), job.seqs.size() * sizeof(cf_seq), st))) return rc;
   if ((rc = c->cf_iws.reserve(job.iws))) return rc;
   if ((rc = c->cf_fws.reserve(job.fws))) return rc;
   if ((rc = c->cf_post.reserve(job.post))) return rc;
@@ -132,7 +132,7 @@ int run_job(dafs_hip_ctx* c, const fold_job& job, const uint8_t* d_codes, const 
   *out = B;
   uint32_t max_len = 0;
   for (const cf_seq& q : job.seqs) max_len = std::max(max_len, q.len);
-  rc = contrafold_launch(B, (uint32_t)job.seqs.size(), max_len, c->stream);
+  rc = contrafold_launch(B, (uint32_t)job.seqs.size(), max_len, st);
   if (!rc && B.stamps) {
     unsigned long long h[8] = {0};
     if (!hip_check(hipMemcpy(h, B.stamps, sizeof h, hipMemcpyDeviceToHost)))
@@ -146,19 +146,39 @@ int run_job(dafs_hip_ctx* c, const fold_job& job, const uint8_t* d_codes, const 
 
 // Batch hook: Fold::Model::calculate(const vector<Fasta>&, vector<BP>&) for -s CONTRAfold.
 // Result: the context's un-relaxed base-pairing store (rows with p > th; reference CUTOFF 0.01).
-extern "C" int dafs_hip_fold_posteriors(dafs_hip_ctx* c, int model, float th) {
+// _begin enqueues the inside/outside/posterior kernels on the context's folding stream and returns; the pair
+// posteriors and the matching-probability transform do not depend on them and may run meanwhile.  _end waits
+// for the kernels and compacts the posteriors into the store.
+extern "C" int dafs_hip_fold_posteriors_begin(dafs_hip_ctx* c, int model, float th) {
   if (!c || c->len.empty() || model != DAFS_FOLD_CONTRAFOLD) return DAFS_HIP_EINVAL;
   if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  if (c->fold_pending) return DAFS_HIP_EINVAL;
   const uint32_t n = (uint32_t)c->len.size();
   fold_job job;
   for (uint32_t x = 0; x < n; ++x) job.add(c->len[x], c->off[x], false, 0);
   cf_batch B;
-  int rc = run_job(c, job, c->codes.ptr, nullptr, &B);
+  int rc = run_job(c, job, c->codes.ptr, nullptr, &B, c->fold_stream);
   if (rc) return rc;
-  bp_store& st = c->bp[0];
-  st.valid = false;
+  c->fold_batch.assign((const uint8_t*)&B, (const uint8_t*)&B + sizeof B);
+  c->fold_pending = true;
+  c->fold_th = th;
+  c->bp[0].valid = false;
   c->bp[1].valid = false;
   c->cur_bp = 0;
+  return DAFS_HIP_OK;
+}
+
+extern "C" int dafs_hip_fold_posteriors_end(dafs_hip_ctx* c) {
+  if (!c || !c->fold_pending || c->fold_batch.size() != sizeof(cf_batch)) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  c->fold_pending = false;
+  if (hip_check(hipStreamSynchronize(c->fold_stream))) return DAFS_HIP_ELAUNCH;
+  cf_batch B;
+  memcpy(&B, c->fold_batch.data(), sizeof B);
+  const float th = c->fold_th;
+  const uint32_t n = (uint32_t)c->len.size();
+  int rc;
+  bp_store& st = c->bp[0];
   if ((rc = st.rowptr.reserve(c->seq_rp_off[n]))) return rc;
   if ((rc = st.nnz.reserve(n))) return rc;
   if ((rc = st.bp_off.reserve(n + 1))) return rc;
@@ -180,6 +200,11 @@ extern "C" int dafs_hip_fold_posteriors(dafs_hip_ctx* c, int model, float th) {
     if (status != DAFS_HIP_EOVERFLOW || attempt >= 4) return status;
     cap = std::max<uint64_t>(h[0], cap * 2);
   }
+}
+
+extern "C" int dafs_hip_fold_posteriors(dafs_hip_ctx* c, int model, float th) {
+  const int rc = dafs_hip_fold_posteriors_begin(c, model, th);
+  return rc ? rc : dafs_hip_fold_posteriors_end(c);
 }
 
 // Single-sequence plugin call: CONTRAfold<float>::ComputePosterior (reference
@@ -205,7 +230,8 @@ extern "C" int dafs_hip_fold_posterior_dense(dafs_hip_ctx* c, const char* seq, u
   fold_job job;
   job.add(len, 0, constraint != nullptr, 0);
   cf_batch B;
-  if ((rc = run_job(c, job, c->cf_codes.ptr, constraint ? c->cf_cons.ptr : nullptr, &B))) return rc;
+  if (c->fold_pending) return DAFS_HIP_EINVAL;  // the batch in flight owns the folding workspaces
+  if ((rc = run_job(c, job, c->cf_codes.ptr, constraint ? c->cf_cons.ptr : nullptr, &B, c->stream))) return rc;
   const uint64_t S = (uint64_t)(len + 1) * (len + 2) / 2;
   if (hip_check(hipMemcpyAsync(post, B.post, S * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
   float z = 0;

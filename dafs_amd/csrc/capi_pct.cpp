@@ -78,7 +78,9 @@ extern "C" int dafs_hip_bp_fetch(dafs_hip_ctx* c, int relaxed, uint32_t* rowptr,
 
 // relax_basepairing_probability then relax_matching_probability, both from the un-relaxed
 // stores (dafs.cpp:1822-1827).  A weight of 0 skips that transform, as the reference does.
-extern "C" int dafs_hip_consistency(dafs_hip_ctx* c, float w_pct_a, float w_pct_s) {
+// which: bit 0 the base-pairing transform, bit 1 the matching transform (the two read only un-relaxed stores, so they
+// may be run in either order, e.g. the matching transform while the folding kernels are still busy)
+static int consistency_parts(dafs_hip_ctx* c, float w_pct_a, float w_pct_s, int which) {
   if (!c || c->len.empty()) return DAFS_HIP_EINVAL;
   if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
   const uint32_t n = (uint32_t)c->len.size();
@@ -90,8 +92,8 @@ extern "C" int dafs_hip_consistency(dafs_hip_ctx* c, float w_pct_a, float w_pct_
   int rc;
   if ((rc = c->counters.reserve(4))) return rc;
 
-  c->cur_bp = 0;
-  if (w_pct_s != 0.0f) {
+  if (which & 1) c->cur_bp = 0;
+  if ((which & 1) && w_pct_s != 0.0f) {
     if (!c->bp[0].valid) return DAFS_HIP_EINVAL;
     bp_store& in = c->bp[0];
     bp_store& out = c->bp[1];
@@ -134,8 +136,8 @@ extern "C" int dafs_hip_consistency(dafs_hip_ctx* c, float w_pct_a, float w_pct_
     c->cur_bp = 1;
   }
 
-  c->cur_mp = 0;
-  if (w_pct_a != 0.0f) {
+  if (which & 2) c->cur_mp = 0;
+  if ((which & 2) && w_pct_a != 0.0f) {
     mp_store& out = c->mp[1];
     out.valid = false;
     out.n_tasks = all;
@@ -198,3 +200,7 @@ extern "C" int dafs_hip_consistency(dafs_hip_ctx* c, float w_pct_a, float w_pct_
   }
   return DAFS_HIP_OK;
 }
+
+extern "C" int dafs_hip_consistency(dafs_hip_ctx* c, float w_pct_a, float w_pct_s) { return consistency_parts(c, w_pct_a, w_pct_s, 3); }
+extern "C" int dafs_hip_consistency_match(dafs_hip_ctx* c, float w_pct_a) { return consistency_parts(c, w_pct_a, 0.0f, 2); }
+extern "C" int dafs_hip_consistency_bp(dafs_hip_ctx* c, float w_pct_s) { return consistency_parts(c, 0.0f, w_pct_s, 1); }

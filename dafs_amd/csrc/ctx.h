@@ -89,6 +89,10 @@ struct dafs_hip_ctx {
   int device = 0;
   int num_cus = 256;  // compute units of the device (co-residency bound of the split node solver)
   hipStream_t stream = nullptr;
+  hipStream_t fold_stream = nullptr;  // the per-sequence folding runs here, beside the pair / consistency kernels
+  bool fold_pending = false;          // dafs_hip_fold_posteriors_begin without its _end
+  float fold_th = 0.0f;
+  std::vector<uint8_t> fold_batch;    // the cf_batch of the pending job (contrafold.h), kept opaque here
   // sequences
   std::string seq;
   std::vector<uint32_t> len, off;

@@ -437,17 +437,24 @@ int run(const Options& o) {
   for (uint i = 0; i < N; ++i) { seqs[i] = fa[i].seq().c_str(); lens[i] = fa[i].size(); }
   check(dafs_hip_set_sequences(ctx, N, seqs.data(), lens.data()));
 
-  // base-pairing probabilities (:1787)
+  // base-pairing probabilities (:1787).  The device folding is only started here: it keeps one workgroup per
+  // sequence busy, and the alignment posteriors and the matching-probability transform run beside it.
+  bool folding = false;
   if (!o.fold_aux.empty()) {
     std::vector<BP> bp;
     load_fold_aux(o.fold_aux, fa, bp);
     upload_bp(ctx, bp);
   } else {
-    check(dafs_hip_fold_posteriors(ctx, DAFS_FOLD_CONTRAFOLD, kCutoff));
+    check(dafs_hip_fold_posteriors_begin(ctx, DAFS_FOLD_CONTRAFOLD, kCutoff));
+    folding = true;
   }
-  if (!o.save_fold_aux.empty()) save_fold_aux(ctx, o.save_fold_aux, fa);
+  auto finish_folding = [&]() {
+    if (folding) { check(dafs_hip_fold_posteriors_end(ctx)); folding = false; }
+    if (!o.save_fold_aux.empty()) save_fold_aux(ctx, o.save_fold_aux, fa);
+  };
 
   std::vector<node_t> tree(1, std::make_pair(0.0f, std::make_pair(-1u, -1u)));
+  if (N == 1) finish_folding();
   if (N > 1) {
     // matching probabilities, transposes, similarities (:1796-1819), PCTs (:1822-1827), tree (:1830)
     if (!o.align_aux.empty()) load_align_aux(ctx, o.align_aux, fa);
@@ -455,7 +462,9 @@ int run(const Options& o) {
     if (!o.save_align_aux.empty()) save_align_aux(ctx, o.save_align_aux, fa);
     std::vector<float> sim((size_t)N * N);
     check(dafs_hip_get_sim(ctx, sim.data()));
-    check(dafs_hip_consistency(ctx, o.align_pct, o.fold_pct));
+    check(dafs_hip_consistency_match(ctx, o.align_pct));
+    finish_folding();
+    check(dafs_hip_consistency_bp(ctx, o.fold_pct));
     tree = build_tree(sim, N);
   }
   print_tree(std::cout, tree, fa, (int)tree.size() - 1);

@@ -198,6 +198,12 @@ int dafs_hip_bp_fetch(dafs_hip_ctx* ctx, int relaxed, uint32_t* rowptr, uint32_t
  * outside / posterior of every sequence on the device, rows with p > th kept (reference CUTOFF
  * 0.01, src/dafs.cpp:1704).  Fills the same store dafs_hip_set_bp fills. */
 int dafs_hip_fold_posteriors(dafs_hip_ctx* ctx, int model, float th);
+/* The same in two halves: _begin enqueues the folding kernels on a stream of their own and returns, _end waits and
+ * fills the store.  Between them the calls that do not need base-pairing probabilities may run (the all-pairs
+ * alignment posteriors, dafs_hip_consistency_match): the folding occupies one workgroup per sequence, which leaves
+ * most of the device idle at N < #CUs. */
+int dafs_hip_fold_posteriors_begin(dafs_hip_ctx* ctx, int model, float th);
+int dafs_hip_fold_posteriors_end(dafs_hip_ctx* ctx);
 /* Single-sequence call replacing CONTRAfold<float>::ComputePosterior (src/contrafold/wrapper.cpp:181-200)
  * and, with a constraint string of len chars from "?.()" ('?' free, '.' unpaired, brackets forced),
  * Fold::Model::calculate(seq, str, bp) (src/fold.cpp:191-207).  post: (len+1)(len+2)/2 floats,
@@ -216,6 +222,9 @@ int dafs_host_build_tree(uint32_t n, const float* sim, float* score, int32_t* le
  * (src/dafs.cpp:1822-1827): both read the un-relaxed stores; weight 0 skips a transform.
  * ---------------------------------------------------------------------------------------- */
 int dafs_hip_consistency(dafs_hip_ctx* ctx, float w_pct_a, float w_pct_s);
+/* the two transforms separately (each reads un-relaxed stores only) */
+int dafs_hip_consistency_match(dafs_hip_ctx* ctx, float w_pct_a);
+int dafs_hip_consistency_bp(dafs_hip_ctx* ctx, float w_pct_s);
 
 /* ------------------------------------------------------------------------------------------
  * L1: decoder plugins on dense row-major matrices (host buffers).
