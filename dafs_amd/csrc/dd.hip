@@ -7,13 +7,20 @@
 //   SparseNussinov::decode (both overloads)                           src/nussinov.cpp:207-392
 //   SparseNeedlemanWunsch::initialize / decode (both overloads)       src/needleman_wunsch.cpp:198-422
 //
-// One workgroup solves one guide-tree node; independent nodes of a batch run side by side.  The
-// whole subgradient loop (up to t_max iterations) stays on the device: per iteration the two
-// Nussinov tables advance together one span-diagonal per barrier, the alignment table one
-// anti-diagonal per barrier, the three tracebacks run on three different wavefronts, and the
-// multiplier update is parallel over the sparse consensus structure.  Float sums that the
-// reference forms sequentially (the dual value s, which steers the step size) are formed in the
+// One workgroup solves one guide-tree node (in split mode three: a leader and one per folding DP);
+// independent nodes of a launch run side by side.  The subgradient loop stays on the device and is
+// resumable: a launch runs at most prm.slice iterations of every node, parks the loop state of the
+// unfinished ones and returns, so the host can merge finished nodes and open their parents without a
+// level barrier (capi_dd.cpp: dafs_hip_nodes_*).  Per iteration the three subproblems run on three
+// wavefronts as skewed, register-resident DPs (lane t owns W columns; the folding DPs sweep rows from the
+// bottom, the alignment DP from the top) with their inputs stored in sweep order, the rows in flight,
+// candidate split points and traceback codes in LDS, followed by their tracebacks (the folding one by the
+// whole wavefront, run by run); the multiplier update is parallel over the sparse consensus structure.
+// Forms that do not fit LDS fall back to the same DPs over HBM/L2 tables (nuss_wave, nw_wave).  Float sums
+// that the reference forms sequentially (the dual value s, which steers the step size) are formed in the
 // same order: positive terms are compacted in consensus-pair order and added by one lane.
+// The standalone decoders (k_nussinov_single, k_nw_single: the plugin entry points and the final consensus
+// structure) use the older barrier-per-diagonal forms below.
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <stdint.h>
