@@ -35,6 +35,7 @@ __device__ __forceinline__ float cf_lpe(float x, float y) { return contra_lpe_t(
 #define CF_MAX_SINGLE 30  // C_MAX_SINGLE_LENGTH, Config.hpp:213
 #define CF_THREADS 256
 
+#define CF_LDS __attribute__((address_space(3)))  // the ring is read on the hottest path: keep its loads ds_*, not flat_*
 struct cf_ctx {  // per-workgroup view
   int L;
   const int* s;          // symbol 0..4 per position 0..L+1 (s[0] = s[L+1] = 4)
@@ -46,7 +47,7 @@ struct cf_ctx {  // per-workgroup view
   // visit only pairable (p+1, q) instead of testing every q.
   const int* plist;
   const int* pcnt;
-  float* ring;           // LDS ring of the last 33 spans of FC (inside) / FCo (outside): ring[(span % 33)*(L+1) + row]; null = none
+  CF_LDS float* ring;    // LDS ring of the last 33 spans of FC (inside) / FCo (outside): ring[(span % 33)*(L+1) + row]; null = none
   const cf_params* P;    // score tables (LDS copy)
   bool free;             // no constraint string: every map entry is -1 and cum is all zero, the lookups are skipped
 };
@@ -101,7 +102,8 @@ __device__ __forceinline__ bool cf_map_ok(const cf_ctx& c, int a, int q) {
   return (ma == -1 || ma == q) && (mq == -1 || mq == a);
 }
 __device__ __forceinline__ float cf_fc_load(const cf_ctx& c, const float* FC, int row, int col) {  // FC[row][col], recent spans from LDS
-  return c.ring ? c.ring[((col - row) % CF_RING) * (c.L + 1) + row] : FC[c.off[row] + col];
+  if (c.ring) return c.ring[((uint32_t)(col - row) % (uint32_t)CF_RING) * (uint32_t)(c.L + 1) + (uint32_t)row];
+  return FC[c.off[row] + col];
 }
 
 // acc (+)= term(0) (+) term(1) ... (+) term(n-1), in that order (Fast_LogPlusEquals is not associative).
@@ -176,7 +178,7 @@ __device__ void cf_inside_cell(const cf_ctx& c, int i, int j, float* FCi, float*
     FCi[off[i] + j] = sum;
     fc = sum;
   }
-  if (c.ring) c.ring[((j - i) % CF_RING) * (L + 1) + i] = fc;
+  if (c.ring) c.ring[((uint32_t)(j - i) % (uint32_t)CF_RING) * (uint32_t)(L + 1) + (uint32_t)i] = fc;
   if (0 < i && i + 2 <= j && j < L) {
     float sum = CONTRA_NEG_INF;
     if (cf_allow_paired(c, i + 1, j))
@@ -250,7 +252,7 @@ __device__ void cf_outside_cell(const cf_ctx& c, int a, int b, const float* FCi,
     }
     FCo[off[a] + b] = fco;
   }
-  if (c.ring) c.ring[((b - a) % CF_RING) * (L + 1) + a] = fco;
+  if (c.ring) c.ring[((uint32_t)(b - a) % (uint32_t)CF_RING) * (uint32_t)(L + 1) + (uint32_t)a] = fco;
 
   // ---- FM1o[a][b]: block 2 of source (a-1,b), block 4 of sources (a,j) j = L..b+1, block 1 of source (a,b)
   float fm1o = CONTRA_NEG_INF;
@@ -327,6 +329,7 @@ __device__ float cf_posterior_cell(const cf_ctx& c, int a, int q, const float* F
 #define CF_INTS(L) (12 * ((L) + 2))
 
 __device__ void cf_bind(cf_ctx& c, int L, int* ints, float* ring, const cf_params* P) {
+  c.ring = (CF_LDS float*)ring;
   c.L = L;
   int* s = ints;
   int* map = s + (L + 2);
@@ -334,7 +337,7 @@ __device__ void cf_bind(cf_ctx& c, int L, int* ints, float* ring, const cf_param
   int* off = cum + (L + 2);
   int* plist = off + (L + 2);
   int* pcnt = plist + 4 * (L + 2);
-  c.s = s; c.map = map; c.cum = cum; c.off = off; c.plist = plist; c.pcnt = pcnt; c.ring = ring; c.P = P;
+  c.s = s; c.map = map; c.cum = cum; c.off = off; c.plist = plist; c.pcnt = pcnt; c.P = P;
 }
 
 __global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B, int use_ring) {
