@@ -486,7 +486,7 @@ int run(const Options& o) {
     // The nodes stay resident on the device (dafs_hip_nodes_*): every round opens the nodes whose children
     // are ready, advances all open nodes by at most kSlice iterations in one launch and merges the
     // finished ones, so a node that needs the full iteration budget does not hold back its level.
-    const uint32_t kSlice = 64;
+    const uint32_t kSlice = 32;
     struct Open { uint node; uint32_t handle; NodeJob job; };
     std::vector<Open> open;
     size_t remaining = tree.size() - N;

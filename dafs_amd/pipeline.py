@@ -85,7 +85,7 @@ class Result:
 
 
 def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25, w_pct_s=0.25, th_a=0.01,
-        th_s=0.2, th_s1=None, align_model=capi.ALIGN_PROBCONS, force_iters=0, timers=None, level_sync=False, slice_iters=64,
+        th_s=0.2, th_s1=None, align_model=capi.ALIGN_PROBCONS, force_iters=0, timers=None, level_sync=False, slice_iters=32,
         mp=None):
     """The whole run.  bp: per-sequence (rowptr, col, val) base-pairing rows (--fold-aux); None
     computes them with the device fold model.  mp: supplied matching probabilities (--align-aux), see Context.set_mp."""
