@@ -355,13 +355,13 @@ int nodes_advance(dafs_hip_ctx* c, uint32_t n, const uint32_t* handles, dd_param
   dp.slice = max_iterations;
   int rc;
   if ((rc = c->d_nodes.upload(nodes.data(), nodes.size(), c->stream))) return rc;
-  if ((rc = dd_solve_launch(c->d_nodes.ptr, (uint32_t)nodes.size(), dp, lds_max, split, c->stream))) return rc;
-  std::vector<uint32_t> info(8 * nodes.size());
-  for (size_t b = 0; b < nodes.size(); ++b)
-    if (hip_check(hipMemcpyAsync(&info[8 * b], nodes[b].info, 32, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+  if ((rc = c->d_paused.reserve(nodes.size()))) return rc;
+  if ((rc = dd_solve_launch(c->d_nodes.ptr, (uint32_t)nodes.size(), dp, lds_max, split, c->d_paused.ptr, c->stream))) return rc;
+  std::vector<uint32_t> paused(nodes.size());
+  if (hip_check(hipMemcpyAsync(paused.data(), c->d_paused.ptr, nodes.size() * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
   if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
   for (size_t b = 0; b < nodes.size(); ++b) {
-    const bool done = info[8 * b + 7] == 0;
+    const bool done = paused[b] == 0;
     c->dd_open[handles[who[b]]].finished = done;
     if (finished) finished[who[b]] = done ? 1 : 0;
   }

@@ -122,6 +122,7 @@ struct dafs_hip_ctx {
   // progressive phase workspaces
   dafs::dev_buf<uint8_t> work, work2;
   dafs::dev_buf<dafs::dd_node> d_nodes;
+  dafs::dev_buf<uint32_t> d_paused;  // per node of a launch: still unfinished
   // resident tree nodes (dafs_hip_nodes_open / _advance / _result / _close): device memory that lives until
   // _close, in large chunks that are kept for the next phase
   struct dd_chunk { uint8_t* ptr; size_t cap, used; };
@@ -145,7 +146,7 @@ struct dafs_hip_ctx {
 
   void free_all() {
     codes.release(); d_len.release(); d_seq_rp_off.release(); tasks.release(); scratch.release(); task_sim.release();
-    counters.release(); d_sim.release(); d_pair_x.release(); d_pair_y.release(); work.release(); work2.release(); d_nodes.release(); dd_release();
+    counters.release(); d_sim.release(); d_pair_x.release(); d_pair_y.release(); work.release(); work2.release(); d_nodes.release(); d_paused.release(); dd_release();
     d_cf_params.release(); cf_seqs.release(); cf_codes.release(); cf_iws.release(); cf_cons.release(); cf_fws.release(); cf_post.release(); cf_logz.release();
     for (int k = 0; k < 2; ++k) { mp[k].release(); bp[k].release(); }
   }

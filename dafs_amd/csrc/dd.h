@@ -69,7 +69,7 @@ int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, h
 #define DD_WREG 8     // widest lane (columns) of the register-resident DP forms
 #define DD_CAP 4  // candidates per column kept in LDS by the fast folding DP
 static const size_t kDdLdsBudget = 156 * 1024;  // dynamic LDS of k_dd_solve (the CU has 160 KB; ~2.2 KB is static)
-int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, bool split, hipStream_t st);
+int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, bool split, uint32_t* d_paused, hipStream_t st);
 // standalone decoders on dense device matrices (one workgroup each)
 int nussinov_launch(uint32_t L, const float* p, const float* q, float w, float th, nuss_ws ws, uint32_t* ss, float* score, hipStream_t st);
 int nw_launch(uint32_t L1, uint32_t L2, const float* p, const float* q, float th, uint32_t* env, int compute_env,

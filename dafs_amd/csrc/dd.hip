@@ -1127,7 +1127,7 @@ __device__ __noinline__ void dd_folder(const dd_node& nd, const dd_params& prm, 
 // ------------------------------------------------------------------------------------------
 // the subgradient loop, dafs.cpp:1066-1294
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, dd_params prm) {
+__global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, dd_params prm, uint32_t* paused_out) {
   const dd_node nd = nodes[blockIdx.x];
   if (blockIdx.y != 0) {  // folding workgroups of a split node
     if (nd.split) dd_folder(nd, prm, blockIdx.y, nd.info[6] != 0 ? nd.info[1] : 0u);
@@ -1452,6 +1452,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
     }
     if (prm.stamps)
       for (int k = 0; k < 6; ++k) nd.info[8 + k] = (resume ? nd.info[8 + k] : 0u) + (uint32_t)tk[k];
+    if (paused_out) paused_out[blockIdx.x] = paused ? 1u : 0u;  // one word per node of the launch: a single copy tells the host who is done
   }
 }
 
@@ -1481,7 +1482,7 @@ int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, h
   hipLaunchKernelGGL(k_node_cbp_fill, dim3(nnodes), dim3(DD_THREADS), 0, st, d_nodes, prm);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
-int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, bool split, hipStream_t st) {
+int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, bool split, uint32_t* d_paused, hipStream_t st) {
   if (!nnodes) return DAFS_HIP_OK;
   static bool attr = false;
   if (!attr) {
@@ -1490,7 +1491,7 @@ int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size
   }
   if (lds_bytes > kDdLdsBudget) return DAFS_HIP_EINVAL;
   // split mode needs the three workgroups of a node on the machine together: the caller keeps 3 * nnodes within the CU count
-  hipLaunchKernelGGL(k_dd_solve, dim3(nnodes, split ? 3 : 1), dim3(DD_THREADS), lds_bytes, st, d_nodes, prm);
+  hipLaunchKernelGGL(k_dd_solve, dim3(nnodes, split ? 3 : 1), dim3(DD_THREADS), lds_bytes, st, d_nodes, prm, d_paused);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 int nussinov_launch(uint32_t L, const float* p, const float* q, float w, float th, nuss_ws ws, uint32_t* ss, float* score, hipStream_t st) {
