@@ -329,6 +329,11 @@ __device__ float nuss_wave(uint32_t L, const float* __restrict__ S, const nuss_w
 // round trips (all candidate keys/values at once, then all dp[i][k-1] at once).
 // Address-space-qualified views: the loops below must compile to ds_* / global_* instructions, not
 // flat_* ones (a flat access waits on both counters, i.e. on the prefetch of the next step as well).
+// lane t receives lane t-1's value, lane 0 receives 0: one DPP move (wave_shr:1) instead of a trip through the
+// LDS crossbar (ds_bpermute), which sits on the step-to-step dependency chain of the wave DPs
+__device__ __forceinline__ float wave_shr1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
 #define DD_LDS __attribute__((address_space(3)))
 #define DD_GLB __attribute__((address_space(1)))
 // The loop must not contain a global store either: on gfx9 loads and stores share vmcnt and complete
@@ -343,10 +348,12 @@ __device__ float nuss_wave_reg(uint32_t L, const float* S_, uint32_t* trb_, floa
   DD_LDS char* ring = (DD_LDS char*)ring_;
   DD_LDS uint32_t* lck = (DD_LDS uint32_t*)lck_;
   DD_LDS uint32_t* trb = (DD_LDS uint32_t*)trb_;  // one nibble per cell of the upper triangle, zeroed by the caller
-  // Per owned column: previous row, score, and the column's candidates as a shift register (slot 0 =
-  // newest; empty slots hold -inf so they never win): value dp[k+1][j-1]+s and the byte offset of
-  // dp[.][k-1] within a row of the ring.  The whole cell is straight-line selects: the lanes of a
-  // wavefront are on different rows and columns, so a branch would be taken by somebody anyway.
+  // Per owned column: previous row, score, and the column's candidates in the order they were found (slot x =
+  // x-th candidate; empty slots hold -inf so they never win): value dp[k+1][j-1]+s and the byte offset of
+  // dp[.][k-1] within a row of the ring.  A single wavefront issues one instruction every four cycles whatever
+  // its kind, so the step is as fast as it is short: the cell is straight-line selects (the lanes are on
+  // different rows and columns, a branch would be taken by somebody anyway) except for the rare insertion of a
+  // new candidate; S holds 0 where j - i < 3 (dd_fill_scores), which stands in for the reference's span test.
   float P[W], Sc[W], nx[W], cvs[W][DD_CAP];
   uint32_t koff[W][DD_CAP], n[W];
 #pragma unroll
@@ -359,10 +366,17 @@ __device__ float nuss_wave_reg(uint32_t L, const float* S_, uint32_t* trb_, floa
   // compiler wait with vmcnt(0) at the first use inside the loop, i.e. for the prefetch just issued
 #pragma unroll
   for (int c = 0; c < W; ++c) asm volatile("" : "+v"(Sc[c]));
-  float last = 0.0f, leftprev = 0.0f, score = 0.0f;
+  float last = 0.0f, leftprev = 0.0f;
   bool ovf = false;
   const int nsteps = (int)L + (int)((L + W - 1) / W) - 1;  // the last lane that owns a column finishes row 0 here
   const int j0 = lane * W;
+  float dknext[W <= 4 ? W : 1][DD_CAP];
+#pragma unroll
+  for (int c = 0; c < (W <= 4 ? W : 1); ++c)
+#pragma unroll
+    for (int x = 0; x < DD_CAP; ++x) dknext[c][x] = 0.0f;  // no candidates yet: every slot pairs with -inf
+  // index of cell (i, i) in the packed triangle, kept by differences: tri(i-1) = tri(i) - (L - (i-1))
+  uint32_t tbase = (uint32_t)(L - 1 + lane) * L - (uint32_t)(L - 1 + lane) * (uint32_t)(L - 2 + lane) / 2;
   for (int s = 0; s < nsteps; ++s) {
     const int i = (int)L - 1 - (s - lane);
     const bool rowv = i >= 0 && i < (int)L;
@@ -370,77 +384,84 @@ __device__ float nuss_wave_reg(uint32_t L, const float* S_, uint32_t* trb_, floa
 #pragma unroll
       for (int c = 0; c < W; ++c) nx[c] = S[((size_t)(s + 1) * W + c) * 64 + lane];
     }
-    float recv = __shfl_up(last, 1);
-    if (lane == 0) recv = 0.0f;
+    const float recv = wave_shr1(last);
     float diag = leftprev;
     float left = recv;
     const uint32_t ui = (uint32_t)i;
     DD_LDS char* rrow = ring + (ui & 63u) * (L * 4);
-    const uint32_t tbase = rowv ? (uint32_t)tri_index(L, ui, ui) : 0u;  // + (j - i)
     const int d0 = j0 - i;
-    if (rowv && (uint32_t)(i - j0) < (uint32_t)W) *(DD_LDS float*)(rrow + ui * 4) = 0.0f;  // dp[i][i], read by candidates of row i+1
-    const bool row0 = rowv && i == 0;
     const uint32_t knew = ui ? (ui - 1) * 4 : 0u;
     // A candidate (k, j) has k <= j - 3, so the column k-1 it reads lies at least four columns to the left of
     // j: with up to four columns per lane it is never one of this lane's own columns of this step, and all
     // the dp[i][k-1] of the step can be fetched in one round trip before the first cell.
-    float dkall[W <= 4 ? W : 1][DD_CAP];
-    if (W <= 4) {
-#pragma unroll
-      for (int c = 0; c < (W <= 4 ? W : 1); ++c)
-#pragma unroll
-        for (int x = 0; x < DD_CAP; ++x) dkall[c][x] = *(DD_LDS const float*)(rrow + koff[c][x]);
-    }
+    // They are in fact fetched at the end of the previous step (dknext): what they read was written by lanes
+    // to the left, which are at least one row ahead, so the values are there by then, and the wait for LDS is
+    // spent on the step's preamble instead of in front of its first cell.
 #pragma unroll
     for (int c = 0; c < W; ++c) {
       const int j = j0 + c, d = d0 + c;
-      const bool valid = rowv && j < (int)L && d >= 1;
+      const bool pub = rowv && j < (int)L && d >= 0;  // cells whose value others read: dp[i][i] = dp[i][i+1] = 0 included
+      const bool act = pub && d >= 2;
       const float below = P[c];
-      const bool m1 = d >= 2;                      // nussinov.cpp:226-233
-      float v = m1 ? below : 0.0f;
-      uint32_t t = m1 ? 1u : 0u;
-      const bool m2 = m1 && v < left;
+      float v = below;                             // nussinov.cpp:226-233
+      uint32_t t = 1u;
+      const bool m2 = v < left;
       v = m2 ? left : v; t = m2 ? 2u : t;
-      const float cand = diag + Sc[c];             // :236
-      const bool create = valid && d >= 3 && Sc[c] > 0.0f;
-      const bool m3 = create && v < cand;
+      const float sc = Sc[c];
+      const float cand = diag + sc;                // :236
+      const bool pos = sc > 0.0f;
+      const bool m3 = pos && v < cand;
       v = m3 ? cand : v; t = m3 ? 3u : t;
-      const uint32_t nc = n[c];
       float dk[DD_CAP];
 #pragma unroll
-      for (int x = 0; x < DD_CAP; ++x) dk[x] = (W <= 4) ? dkall[c][x] : *(DD_LDS const float*)(rrow + koff[c][x]);  // all dp[i][k-1] in one round trip
+      for (int x = 0; x < DD_CAP; ++x) dk[x] = (W <= 4) ? dknext[c][x] : *(DD_LDS const float*)(rrow + koff[c][x]);  // all dp[i][k-1] in one round trip
 #pragma unroll
-      for (int x = DD_CAP - 1; x >= 0; --x) {      // bifurcations, oldest candidate first (:245-255)
+      for (int x = 0; x < DD_CAP; ++x) {           // bifurcations, oldest candidate first (:245-255)
         const float cx = dk[x] + cvs[c][x];
         const bool m = v < cx;
         v = m ? cx : v; t = m ? (uint32_t)(4 + x) : t;
       }
-      t = t >= 4 ? nc + 7 - t : t;                 // slot -> 4 + insertion index
-      if (valid) {
+      v = act ? v : 0.0f;
+      t = act ? t : 0u;
+      if (pub) {
         *(DD_LDS float*)(rrow + j * 4) = v;
         const uint32_t q = tbase + (uint32_t)d;
         __hip_atomic_fetch_or(&trb[q >> 3], t << ((q & 7u) * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      if (create) {
+      if (act && pos) {                            // a new candidate for column j
+        const uint32_t nc = n[c];
         if (nc < DD_CAP) lck[nc * L + j] = ui; else ovf = true;
-      }
-      n[c] = (create && nc < DD_CAP) ? nc + 1 : nc;
 #pragma unroll
-      for (int x = DD_CAP - 1; x >= 1; --x) { cvs[c][x] = create ? cvs[c][x - 1] : cvs[c][x]; koff[c][x] = create ? koff[c][x - 1] : koff[c][x]; }
-      cvs[c][0] = create ? cand : cvs[c][0];
-      koff[c][0] = create ? knew : koff[c][0];
-      v = valid ? v : 0.0f;
-      if (row0 && j == (int)L - 1) score = v;
+        for (int x = 0; x < DD_CAP; ++x) {
+          const bool here = nc == (uint32_t)x;
+          cvs[c][x] = here ? cand : cvs[c][x];
+          koff[c][x] = here ? knew : koff[c][x];
+        }
+        n[c] = nc + 1;
+      }
       diag = below;
       P[c] = v;
       left = v;
     }
     leftprev = recv;
     last = left;
+    tbase = tbase + ui - (L + 1);
 #pragma unroll
     for (int c = 0; c < W; ++c) Sc[c] = nx[c];
+    if (W <= 4) {  // the next step's dp[i-1][k-1], with this step's new candidates included
+      DD_LDS const char* nrow = ring + ((ui - 1u) & 63u) * (L * 4);
+#pragma unroll
+      for (int c = 0; c < (W <= 4 ? W : 1); ++c)
+#pragma unroll
+        for (int x = 0; x < DD_CAP; ++x) dknext[c][x] = *(DD_LDS const float*)(nrow + koff[c][x]);
+    }
   }
   *ovf_out = __any(ovf);
+  // dp[0][L-1]: what the lane that owns the last column holds after its last step
+  float score = 0.0f;
+#pragma unroll
+  for (int c = 0; c < W; ++c)
+    if ((uint32_t)c == (L - 1) % (uint32_t)W) score = P[c];
   return __shfl(score, (int)((L - 1) / W));
 }
 
@@ -536,7 +557,7 @@ __device__ float nw_wave_reg(uint32_t L1, uint32_t L2, const float* ps_, const f
     }
     const bool nrow = i + 1 >= 1 && i + 1 <= (int)L1;
     const uint32_t nef = nrow ? env[2 * (i + 1)] : 1u, nes = nrow ? env[2 * (i + 1) + 1] : 0u;
-    const float recv = __shfl_up(last, 1);
+    const float recv = wave_shr1(last);  // lane 0 owns column 0, which takes nothing from its left
     float diag = leftprev;
     float left = recv;
     float v = 0.0f;
@@ -602,7 +623,7 @@ __device__ void dd_fill_scores(uint32_t L, const float* __restrict__ p, const fl
   const uint32_t W = (L + 63) / 64;
   for (size_t c = threadIdx.x; c < (size_t)L * L; c += blockDim.x) {
     const uint32_t i = (uint32_t)(c / L), j = (uint32_t)(c - (size_t)i * L);
-    S[nuss_skew(L, W, i, j)] = w * (p[c] - th) - q[c];
+    S[nuss_skew(L, W, i, j)] = j >= i + 3 ? w * (p[c] - th) - q[c] : 0.0f;  // a pair spans at least three (nussinov.cpp:236 is inside the span loop)
   }
 }
 __device__ void dd_fill_nw(uint32_t L1, uint32_t L2, const float* __restrict__ p, const float* __restrict__ q, float* ps, float* qs) {
@@ -1342,7 +1363,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
           const size_t o = (size_t)i * L1 + j;
           const float qn = nd.q_x[o] - eta * (tc - 1);
           nd.q_x[o] = qn;
-          nd.s_x[nuss_skew(L1, Wx, i, j)] = w_x * (nd.p_x[o] - prm.th_s) - qn;
+          if (j >= i + 3) nd.s_x[nuss_skew(L1, Wx, i, j)] = w_x * (nd.p_x[o] - prm.th_s) - qn;
         }
       }
       for (uint32_t e = nd.px_ptr[i]; e < nd.px_ptr[i + 1]; ++e) {
@@ -1354,7 +1375,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
           const size_t o = (size_t)i * L1 + jj;
           const float qn = nd.q_x[o] - eta * tc;
           nd.q_x[o] = qn;
-          nd.s_x[nuss_skew(L1, Wx, i, jj)] = w_x * (nd.p_x[o] - prm.th_s) - qn;
+          if (jj >= i + 3) nd.s_x[nuss_skew(L1, Wx, i, jj)] = w_x * (nd.p_x[o] - prm.th_s) - qn;  // shorter spans stay 0 (dd_fill_scores)
         }
       }
       const uint32_t kz = nd.z[i];
@@ -1389,7 +1410,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
           const size_t o = (size_t)k * L2 + l;
           const float qn = nd.q_y[o] - eta * (tc - 1);
           nd.q_y[o] = qn;
-          nd.s_y[nuss_skew(L2, Wy, k, l)] = w_y * (nd.p_y[o] - prm.th_s) - qn;
+          if (l >= k + 3) nd.s_y[nuss_skew(L2, Wy, k, l)] = w_y * (nd.p_y[o] - prm.th_s) - qn;
         }
       }
       for (uint32_t e = nd.py_ptr[k]; e < nd.py_ptr[k + 1]; ++e) {
@@ -1401,7 +1422,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
           const size_t o = (size_t)k * L2 + ll;
           const float qn = nd.q_y[o] - eta * tc;
           nd.q_y[o] = qn;
-          nd.s_y[nuss_skew(L2, Wy, k, ll)] = w_y * (nd.p_y[o] - prm.th_s) - qn;
+          if (ll >= k + 3) nd.s_y[nuss_skew(L2, Wy, k, ll)] = w_y * (nd.p_y[o] - prm.th_s) - qn;
         }
       }
     }

@@ -129,6 +129,7 @@ def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25
     pending = [i for i in range(n, 2 * n - 1)]
     prm = capi.dd_params(w=w, eta0=eta0, th_a=th_a, th_s=th_s, t_max=t_max, force_iters=force_iters)
     res.dd_log = {}
+    res.dd_dims = {}  # node -> (columns of the left, of the right alignment); resident-node mode only
     res.levels = 0
     if level_sync:
         while pending:
@@ -158,6 +159,7 @@ def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25
                 o = ctx.nodes_result(h, l1, l2)
                 aln[i] = project_alignment(aln[left[i]], aln[right[i]], o["z"])
                 res.dd_log[i] = (o["iterations"], o["violated"], o["ncbp"], o["score"])
+                res.dd_dims[i] = (l1, l2)
                 del aln[left[i]], aln[right[i]]
             res.levels += 1
         ctx.nodes_close()
