@@ -34,6 +34,10 @@ __device__ __forceinline__ float cf_lpe(float x, float y) { return contra_lpe_t(
 
 #define CF_MAX_SINGLE 30  // C_MAX_SINGLE_LENGTH, Config.hpp:213
 #define CF_THREADS 256
+// k_contrafold: the cells of a span are dealt round-robin to 16 wavefronts (cell -> lane*16 + wavefront), so a
+// span of 150 cells keeps four wavefronts per SIMD busy with ~10 lanes each instead of three wavefronts in all:
+// the inner loops are chains of dependent LDS lookups, and it is the number of wavefronts that hides them
+#define CF_FOLD_THREADS 1024
 
 #define CF_LDS __attribute__((address_space(3)))  // the ring is read on the hottest path: keep its loads ds_*, not flat_*
 struct cf_ctx {  // per-workgroup view
@@ -340,10 +344,10 @@ __device__ void cf_bind(cf_ctx& c, int L, int* ints, float* ring, const cf_param
   c.s = s; c.map = map; c.cum = cum; c.off = off; c.plist = plist; c.pcnt = pcnt; c.P = P;
 }
 
-__global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B, int use_ring) {
+__global__ __launch_bounds__(CF_FOLD_THREADS) void k_contrafold(cf_batch B, int use_ring) {
   CF_TABLES_INIT();
   __shared__ cf_params sP;
-  __shared__ float s_terms[CF_THREADS];
+  __shared__ float s_terms[CF_FOLD_THREADS];
   {
     const float* src = (const float*)B.params;
     float* dst = (float*)&sP;
@@ -353,6 +357,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B, int use_r
   const cf_seq sq = B.seqs[x];
   const int L = (int)sq.len;
   const int tid = threadIdx.x, nt = blockDim.x;
+  const int cid = (tid & 63) * (nt >> 6) + (tid >> 6);  // this thread's place in a span (see CF_FOLD_THREADS)
   extern __shared__ int s_ints[];
   float* ring = use_ring ? (float*)(s_ints + CF_INTS(L)) : nullptr;
   cf_ctx c;
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B, int use_r
   CF_STAMP(0);
   // ---- inside: span ascending
   for (int d = 0; d <= L; ++d) {
-    for (int i = tid; i + d <= L; i += nt) cf_inside_cell(c, i, i + d, FCi, FMi, FM1i);
+    for (int i = cid; i + d <= L; i += nt) cf_inside_cell(c, i, i + d, FCi, FMi, FM1i);
     __syncthreads();
   }
   CF_STAMP(1);
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B, int use_r
   __syncthreads();
   for (int j = L; j >= 1; --j) {
     const float f5oj = F5o[j];
-    for (int k = tid; k < j; k += nt) {
+    for (int k = cid; k < j; k += nt) {
       float v = F5o[k];
       if (k == j - 1 && cf_unpaired_pos(c, j)) v = cf_lpe(v, f5oj + EXT_UNPAIRED);
       if (cf_allow_paired(c, k + 1, j)) {
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_contrafold(cf_batch B, int use_r
   CF_STAMP(3);
   // main sweep: span descending
   for (int d = L; d >= 0; --d) {
-    for (int a = tid; a + d <= L; a += nt) cf_outside_cell(c, a, a + d, FCi, FMi, FM1i, F5i, F5o, FCo, FMo, FM1o, FM2o);
+    for (int a = cid; a + d <= L; a += nt) cf_outside_cell(c, a, a + d, FCi, FMi, FM1i, F5i, F5o, FCo, FMo, FM1o, FM2o);
     __syncthreads();
   }
   CF_STAMP(4);
@@ -548,7 +553,7 @@ int contrafold_launch(const cf_batch& B, uint32_t nseq, uint32_t max_len, hipStr
     if (hip_check(hipFuncSetAttribute((const void*)k_contrafold_posterior, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget))) return DAFS_HIP_ELAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL(k_contrafold, dim3(nseq), dim3(CF_THREADS), lds, st, B, use_ring);
+  hipLaunchKernelGGL(k_contrafold, dim3(nseq), dim3(CF_FOLD_THREADS), lds, st, B, use_ring);
   if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
   hipLaunchKernelGGL(k_contrafold_posterior, dim3(max_len + 1, nseq), dim3(CF_THREADS), ints, st, B);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
