@@ -186,6 +186,7 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
 
   // ---- carve each node's block (two passes: size, then pointers) ----
   std::vector<dd_node> nodes(nnodes);
+  std::vector<std::vector<uint8_t>> heads(nnodes);  // upload staging, alive until the first synchronisation below
   std::vector<size_t> lds(nnodes, 0), split_lds(nnodes, 0);
   for (uint32_t b = 0; b < nnodes; ++b) {
     const dafs_node_input& ni = in[b];
@@ -209,6 +210,7 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
       nd.q_x = cv.take<float>(XX); nd.q_y = cv.take<float>(YY); nd.q_z = cv.take<float>(ZZ);
       nd.cz_flag = cv.take<uint8_t>(ZZ);
       nd.cx_flag = cv.take<uint8_t>(XX / 2 + 2); nd.cy_flag = cv.take<uint8_t>(YY / 2 + 2);
+      nd.sync = cv.take<uint32_t>(8);
       fills.push_back({z0, cv.used - z0, 0});
       // -1-filled block: dense id maps
       const size_t m0 = (cv.used + 255) & ~(size_t)255;
@@ -267,7 +269,7 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
       nd.cbp_cnt = cv.take<uint32_t>(XX / 2 + 2);
       nd.tx = cv.take<int32_t>(XX / 2 + 2); nd.ty = cv.take<int32_t>(YY / 2 + 2); nd.tz = cv.take<int32_t>(ZZ + 1);
       nd.x = cv.take<uint32_t>((size_t)L1 + 2); nd.y = cv.take<uint32_t>((size_t)L2 + 2); nd.z = cv.take<uint32_t>((size_t)L1 + 2);
-      nd.score = cv.take<float>(1); nd.info = cv.take<uint32_t>(16); nd.fstate = cv.take<float>(4); nd.sync = cv.take<uint32_t>(8);
+      nd.score = cv.take<float>(1); nd.info = cv.take<uint32_t>(16); nd.fstate = cv.take<float>(4);
       if (pass == 0) {
         cv.base = c->dd_alloc(cv.used + 256);
         if (!cv.base) return DAFS_HIP_ENOMEM;
@@ -275,15 +277,20 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
     }
     for (const region& r : fills)
       if (hip_check(hipMemsetAsync(cv.base + r.off, r.value, r.bytes, c->stream))) return DAFS_HIP_ELAUNCH;
-    if (hip_check(hipMemsetAsync(nd.sync, 0, 32, c->stream))) return DAFS_HIP_ELAUNCH;
-    auto up = [&](const void* dst, const void* src, size_t bytes) {
-      return bytes == 0 || !hip_check(hipMemcpyAsync((void*)dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-    };
-    bool ok = up(nd.seq1, ni.seq1, ni.n1 * 4) && up(nd.seq2, ni.seq2, ni.n2 * 4) &&
-              up(nd.rank1, g1[b].rank.data(), g1[b].rank.size() * 4) && up(nd.rank2, g2[b].rank.data(), g2[b].rank.size() * 4) &&
-              up(nd.idx1, g1[b].idx.data(), g1[b].idx.size() * 4) && up(nd.idx2, g2[b].idx.data(), g2[b].idx.size() * 4) &&
-              up(nd.idxoff1, g1[b].idxoff.data(), ni.n1 * 4) && up(nd.idxoff2, g2[b].idxoff.data(), ni.n2 * 4);
-    if (!ok) return DAFS_HIP_ELAUNCH;
+    // the geometry arrays were carved first and back to back: one upload of the head of the block brings them all
+    {
+      const size_t head = (size_t)((const uint8_t*)(nd.idxoff2 + ni.n2) - cv.base);
+      std::vector<uint8_t>& blob = heads[b];
+      blob.assign(head, 0);
+      auto put = [&](const void* dst, const void* src, size_t bytes) {
+        if (bytes) memcpy(blob.data() + ((const uint8_t*)dst - cv.base), src, bytes);
+      };
+      put(nd.seq1, ni.seq1, (size_t)ni.n1 * 4); put(nd.seq2, ni.seq2, (size_t)ni.n2 * 4);
+      put(nd.rank1, g1[b].rank.data(), g1[b].rank.size() * 4); put(nd.rank2, g2[b].rank.data(), g2[b].rank.size() * 4);
+      put(nd.idx1, g1[b].idx.data(), g1[b].idx.size() * 4); put(nd.idx2, g2[b].idx.data(), g2[b].idx.size() * 4);
+      put(nd.idxoff1, g1[b].idxoff.data(), (size_t)ni.n1 * 4); put(nd.idxoff2, g2[b].idxoff.data(), (size_t)ni.n2 * 4);
+      if (hip_check(hipMemcpyAsync(cv.base, blob.data(), head, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
+    }
   }
   int rc;
   if ((rc = c->d_nodes.upload(nodes.data(), nnodes, c->stream))) return rc;  // synchronises: host vectors stay valid until here
@@ -292,14 +299,14 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
   uint32_t max_len = 0;
   for (uint32_t b = 0; b < nnodes; ++b) max_len = std::max(max_len, std::max(in[b].len1, in[b].len2));
   if ((rc = dd_avg_launch(c->d_nodes.ptr, nnodes, max_len, mpv, bpv, c->stream))) return rc;
-  if ((rc = dd_lists_launch(c->d_nodes.ptr, nnodes, dp, c->stream))) return rc;
+  if ((rc = c->d_paused.reserve(nnodes))) return rc;  // doubles as the landing place of the per-node counts
+  if ((rc = dd_lists_launch(c->d_nodes.ptr, nnodes, dp, c->d_paused.ptr, c->stream))) return rc;
   // ---- consensus base-pair counts -> each node's second block ----
-  std::vector<uint32_t> info(4 * (size_t)nnodes);
-  for (uint32_t b = 0; b < nnodes; ++b)
-    if (hip_check(hipMemcpyAsync(&info[4 * (size_t)b], nodes[b].info, 16, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+  std::vector<uint32_t> counts(nnodes);
+  if (hip_check(hipMemcpyAsync(counts.data(), c->d_paused.ptr, (size_t)nnodes * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
   if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
   for (uint32_t b = 0; b < nnodes; ++b) {
-    const uint32_t ncbp = info[4 * (size_t)b];
+    const uint32_t ncbp = counts[b];
     carver cb;
     for (int pass = 0; pass < 2; ++pass) {
       cb.used = 0;

@@ -553,7 +553,12 @@ int contrafold_launch(const cf_batch& B, uint32_t nseq, uint32_t max_len, hipStr
     if (hip_check(hipFuncSetAttribute((const void*)k_contrafold_posterior, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget))) return DAFS_HIP_ELAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL(k_contrafold, dim3(nseq), dim3(CF_FOLD_THREADS), lds, st, B, use_ring);
+  int fold_threads = CF_FOLD_THREADS;
+  if (const char* e = getenv("DAFS_HIP_CF_THREADS")) {  // tuning aid: 64..1024 in whole wavefronts
+    const int v = atoi(e);
+    if (v >= 64 && v <= CF_FOLD_THREADS && v % 64 == 0) fold_threads = v;
+  }
+  hipLaunchKernelGGL(k_contrafold, dim3(nseq), dim3(fold_threads), lds, st, B, use_ring);
   if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
   hipLaunchKernelGGL(k_contrafold_posterior, dim3(max_len + 1, nseq), dim3(CF_THREADS), ints, st, B);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;

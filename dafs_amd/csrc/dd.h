@@ -63,7 +63,7 @@ struct dd_params {
 };
 
 int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_store_dev mp, bp_store_dev bp, hipStream_t st);
-int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st);
+int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, uint32_t* d_ncbp, hipStream_t st);  // d_ncbp[b]: consensus pairs of node b
 int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st);
 #define DD_LMAX 4096  // longest child alignment the node kernels take (64 lanes x 64 columns; LDS row buffers)
 #define DD_WREG 8     // widest lane (columns) of the register-resident DP forms

@@ -966,7 +966,7 @@ __device__ __forceinline__ uint32_t row_of_entry(const uint32_t* ptr, uint32_t R
   return lo;
 }
 
-__global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes, dd_params prm) {
+__global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes, dd_params prm, uint32_t* ncbp_out) {
   const dd_node nd = nodes[blockIdx.x];
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const uint32_t L1 = nd.L1, L2 = nd.L2;
@@ -1006,6 +1006,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes,
   nw_envelope(L1, L2, nd.p_z, prm.th_a, nd.env, nd.x, nd.z);  // x / z double as scratch here
   nw_init(L1, L2, nd.dp_z, nd.tr_z);
   __syncthreads();
+  if (tid == 0 && ncbp_out) ncbp_out[blockIdx.x] = s_total;  // the host sizes the constraint block from this (one copy per call)
   if (tid == 0) { nd.info[0] = s_total; nd.info[1] = 0; nd.info[2] = 0; nd.info[3] = 0; nd.info[4] = 0; nd.info[5] = 0; nd.info[6] = 0; nd.info[7] = 0; }
 }
 
@@ -1493,9 +1494,9 @@ int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_
   hipLaunchKernelGGL(k_node_avg, dim3((max_len + 3) / 4, nnodes, 3), dim3(256), lds, st, d_nodes, mp, bp, row_cap);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
-int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st) {
+int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, uint32_t* d_ncbp, hipStream_t st) {
   if (!nnodes) return DAFS_HIP_OK;
-  hipLaunchKernelGGL(k_node_lists, dim3(nnodes), dim3(DD_THREADS), 0, st, d_nodes, prm);
+  hipLaunchKernelGGL(k_node_lists, dim3(nnodes), dim3(DD_THREADS), 0, st, d_nodes, prm, d_ncbp);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st) {
