@@ -223,40 +223,37 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
       nd.s_x = cv.take<float>(((size_t)L1 + 63) * ((L1 + 63) / 64) * 64); nd.s_y = cv.take<float>(((size_t)L2 + 63) * ((L2 + 63) / 64) * 64);
       nd.pz_s = cv.take<float>(((size_t)L1 + 63) * ((L2 + 64) / 64) * 64); nd.qz_s = cv.take<float>(((size_t)L1 + 63) * ((L2 + 64) / 64) * 64);
       nd.trk_x = nd.wx.tr; nd.trk_y = nd.wy.tr;  // the L*L uint32 tables double as bifurcation codes
-      {  // LDS plan: previous-row buffers + candidate counters of the HBM-table forms, then the on-chip forms
-        size_t used = ((size_t)(2 * ((L1 + 63) / 64) + 2 * ((L2 + 63) / 64) + 3 * ((L2 + 64) / 64)) * 64 + L1 + L2) * 4;
-        // granted in order of payoff: the fast x and y folding DPs (bits 1, 2: packed traceback nibbles, the 64
-        // rows in flight, DD_CAP split rows per column), then the packed alignment traceback (bit 0)
-        const size_t need[3] = {(((size_t)T + 15) / 16) * 4, (((size_t)L1 * (L1 + 1) / 2 + 7) / 8 + (size_t)L1 * (64 + DD_CAP)) * 4,
-                                (((size_t)L2 * (L2 + 1) / 2 + 7) / 8 + (size_t)L2 * (64 + DD_CAP)) * 4};
-        static const int order[3] = {1, 2, 0};
+      {  // LDS plan (mirrors the carving at the top of k_dd_solve / dd_folder)
+        const size_t base_z = (size_t)3 * ((L2 + 64) / 64) * 64 * 4;                       // row buffers of the alignment DP
+        const size_t slow_x = (size_t)dd_slow_words(L1) * 4, slow_y = (size_t)dd_slow_words(L2) * 4;  // HBM-table folding forms
+        auto nib = [](uint32_t L) { return ((size_t)L * (L + 1) / 2 + 7) / 8; };           // packed traceback codes, words
+        // a fast folding DP: codes, the rows in flight (one per active lane), DD_CAP split rows per column
+        auto fast = [&](uint32_t L) { return (nib(L) + dd_ring_words(L) + (size_t)DD_CAP * L) * 4; };
+        const size_t need_z = (((size_t)T + 15) / 16) * 4;                                   // packed alignment traceback
+        const uint32_t Lm = std::max(L1, L2);
+        const size_t shared = (std::max(nib(L1), nib(L2)) + std::max(dd_ring_words(L1), dd_ring_words(L2)) + (size_t)DD_CAP * Lm) * 4;
+        const size_t shared_g = (std::max(dd_ring_words(L1), dd_ring_words(L2)) + (size_t)DD_CAP * Lm) * 4;
+        auto fast_g = [&](uint32_t L) { return ((size_t)dd_ring_words(L) + (size_t)DD_CAP * L) * 4; };  // traceback codes in HBM
+        size_t used = base_z;
         nd.lds_flags = 0;
-        if (used + need[1] + need[2] <= kDdLdsBudget) {
-          for (int o = 0; o < 3; ++o) {
-            const int k = order[o];
-            if (used + need[k] <= kDdLdsBudget) { used += need[k]; nd.lds_flags |= 1u << k; }
-          }
-        } else {
-          // both folding DPs do not fit side by side: one region for the two of them, x first, then y (bit 3)
-          const uint32_t Lm = std::max(L1, L2);
-          const size_t shared = (((size_t)Lm * (Lm + 1) / 2 + 7) / 8 + (size_t)Lm * (64 + DD_CAP)) * 4;
-          if (Lm <= 64 * DD_WREG && used + shared <= kDdLdsBudget) { used += shared; nd.lds_flags |= 8u; }
-          if (used + need[0] <= kDdLdsBudget) { used += need[0]; nd.lds_flags |= 1u; }
-        }
+        if (used + fast(L1) + fast(L2) <= kDdLdsBudget) { used += fast(L1) + fast(L2); nd.lds_flags = 2u | 4u; }  // x and y side by side
+        else if (Lm <= 64 * DD_WREG && used + shared <= kDdLdsBudget) { used += shared; nd.lds_flags = 8u; }      // one region, x then y
+        else if (Lm <= 64 * DD_WREG && used + shared_g <= kDdLdsBudget) { used += shared_g; nd.lds_flags = 8u | 16u; }  // the same, codes in HBM
+        else used += slow_x + slow_y;
+        if (used + need_z <= kDdLdsBudget) { used += need_z; nd.lds_flags |= 1u; }
         lds[b] = used;
         // split plan: each folding DP on a workgroup of its own.  Worth it when the two do not run side by side
         // in one workgroup; the leader then keeps only the alignment DP (its LDS need is covered by `used`).
         nd.split = 0; nd.fold_fast = 0;
         split_lds[b] = 0;
-        if (!(nd.lds_flags & 2) || !(nd.lds_flags & 4)) {
+        if (!(nd.lds_flags & 2)) {
           size_t worst = 0;
           const uint32_t Ls[2] = {L1, L2};
           for (int r = 0; r < 2; ++r) {
             const uint32_t L = Ls[r];
-            const size_t basef = ((size_t)2 * ((L + 63) / 64) * 64 + L) * 4;
-            const size_t fast = (((size_t)L * (L + 1) / 2 + 7) / 8 + (size_t)L * (64 + DD_CAP)) * 4;
-            if (L <= 64 * DD_WREG && basef + fast <= kDdLdsBudget) { nd.fold_fast |= 1u << r; worst = std::max(worst, basef + fast); }
-            else worst = std::max(worst, basef);
+            if (L <= 64 * DD_WREG && fast(L) <= kDdLdsBudget) { nd.fold_fast |= 1u << r; worst = std::max(worst, fast(L)); }
+            else if (L <= 64 * DD_WREG && fast_g(L) <= kDdLdsBudget) { nd.fold_fast |= 4u << r; worst = std::max(worst, fast_g(L)); }
+            else worst = std::max(worst, (size_t)dd_slow_words(L) * 4);
           }
           if (nd.fold_fast) split_lds[b] = std::max(worst, used);
         }

@@ -68,6 +68,16 @@ int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, h
 #define DD_LMAX 4096  // longest child alignment the node kernels take (64 lanes x 64 columns; LDS row buffers)
 #define DD_WREG 8     // widest lane (columns) of the register-resident DP forms
 #define DD_CAP 4  // candidates per column kept in LDS by the fast folding DP
+// LDS words of the in-flight rows of a fast folding DP: one row of L values per active lane (the lanes own
+// ceil(L/64) columns each, so ceil(L / that) of them are at work).  The previous-row buffers and candidate counters of
+// the HBM-table form borrow the same words when that form has to run (the ring is idle then), hence the floor.
+static inline __host__ __device__ uint32_t dd_fold_cols(uint32_t L) { return (L + 63) / 64; }
+static inline __host__ __device__ uint32_t dd_ring_rows(uint32_t L) { const uint32_t W = dd_fold_cols(L); return W ? (L + W - 1) / W : 0; }
+static inline __host__ __device__ uint32_t dd_slow_words(uint32_t L) { return 2 * dd_fold_cols(L) * 64 + L; }
+static inline __host__ __device__ uint32_t dd_ring_words(uint32_t L) {
+  const uint32_t a = dd_ring_rows(L) * L, b = dd_slow_words(L);
+  return a > b ? a : b;
+}
 static const size_t kDdLdsBudget = 156 * 1024;  // dynamic LDS of k_dd_solve (the CU has 160 KB; ~2.2 KB is static)
 int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, bool split, uint32_t* d_paused, hipStream_t st);
 // standalone decoders on dense device matrices (one workgroup each)

@@ -342,8 +342,14 @@ __device__ __forceinline__ float wave_shr1(float v) {
 // is recorded as 4 + its candidate slot, the split row is read back from lck), and a column that
 // collects more than DD_CAP candidates raises `ovf`; the caller then repeats the DP with
 // nuss_wave, which works in global memory.
-template <int W>
-__device__ float nuss_wave_reg(uint32_t L, const float* S_, uint32_t* trb_, float* ring_, uint32_t* lck_, int lane, bool* ovf_out) {
+// TRG: the traceback codes go to HBM instead (one byte per cell of the upper triangle, trbg_) for alignments whose
+// nibble table no longer fits beside the rows in flight.  That puts stores into the loop, so every wait for the
+// prefetched scores also waits for them; with the seven or more cells per lane of such alignments a step is
+// longer than the trip to L2 and the wait is over before it starts.
+template <int W, bool TRG>
+__device__ float nuss_wave_reg(uint32_t L, const float* S_, uint32_t* trb_, uint8_t* trbg_, float* ring_, uint32_t* lck_, int lane, bool* ovf_out) {
+  DD_GLB uint8_t* trbg = (DD_GLB uint8_t*)trbg_;
+  const uint32_t R = dd_ring_rows(L);  // rows in flight = lanes at work; row i lives in slot i mod R
   DD_GLB const float* S = (DD_GLB const float*)S_;
   DD_LDS char* ring = (DD_LDS char*)ring_;
   DD_LDS uint32_t* lck = (DD_LDS uint32_t*)lck_;
@@ -377,6 +383,7 @@ __device__ float nuss_wave_reg(uint32_t L, const float* S_, uint32_t* trb_, floa
     for (int x = 0; x < DD_CAP; ++x) dknext[c][x] = 0.0f;  // no candidates yet: every slot pairs with -inf
   // index of cell (i, i) in the packed triangle, kept by differences: tri(i-1) = tri(i) - (L - (i-1))
   uint32_t tbase = (uint32_t)(L - 1 + lane) * L - (uint32_t)(L - 1 + lane) * (uint32_t)(L - 2 + lane) / 2;
+  uint32_t rslot = (uint32_t)(L - 1 + lane) % R;  // slot of this step's row, stepped down with the row
   for (int s = 0; s < nsteps; ++s) {
     const int i = (int)L - 1 - (s - lane);
     const bool rowv = i >= 0 && i < (int)L;
@@ -388,7 +395,7 @@ __device__ float nuss_wave_reg(uint32_t L, const float* S_, uint32_t* trb_, floa
     float diag = leftprev;
     float left = recv;
     const uint32_t ui = (uint32_t)i;
-    DD_LDS char* rrow = ring + (ui & 63u) * (L * 4);
+    DD_LDS char* rrow = ring + rslot * (L * 4);
     const int d0 = j0 - i;
     const uint32_t knew = ui ? (ui - 1) * 4 : 0u;
     // A candidate (k, j) has k <= j - 3, so the column k-1 it reads lies at least four columns to the left of
@@ -426,7 +433,8 @@ __device__ float nuss_wave_reg(uint32_t L, const float* S_, uint32_t* trb_, floa
       if (pub) {
         *(DD_LDS float*)(rrow + j * 4) = v;
         const uint32_t q = tbase + (uint32_t)d;
-        __hip_atomic_fetch_or(&trb[q >> 3], t << ((q & 7u) * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (TRG) trbg[q] = (uint8_t)t;
+        else __hip_atomic_fetch_or(&trb[q >> 3], t << ((q & 7u) * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       if (act && pos) {                            // a new candidate for column j
         const uint32_t nc = n[c];
@@ -448,8 +456,9 @@ __device__ float nuss_wave_reg(uint32_t L, const float* S_, uint32_t* trb_, floa
     tbase = tbase + ui - (L + 1);
 #pragma unroll
     for (int c = 0; c < W; ++c) Sc[c] = nx[c];
+    rslot = rslot ? rslot - 1 : R - 1;
     if (W <= 4) {  // the next step's dp[i-1][k-1], with this step's new candidates included
-      DD_LDS const char* nrow = ring + ((ui - 1u) & 63u) * (L * 4);
+      DD_LDS const char* nrow = ring + rslot * (L * 4);
 #pragma unroll
       for (int c = 0; c < (W <= 4 ? W : 1); ++c)
 #pragma unroll
@@ -465,17 +474,22 @@ __device__ float nuss_wave_reg(uint32_t L, const float* S_, uint32_t* trb_, floa
   return __shfl(score, (int)((L - 1) / W));
 }
 
-__device__ __noinline__ float nuss_wave_fast(uint32_t W, uint32_t L, const float* S, uint32_t* trb, float* ring, uint32_t* lck, int lane, bool* ovf) {
+template <bool TRG>
+__device__ __noinline__ float nuss_wave_fast_t(uint32_t W, uint32_t L, const float* S, uint32_t* trb, uint8_t* trbg, float* ring, uint32_t* lck, int lane, bool* ovf) {
   switch (W) {
-    case 1: return nuss_wave_reg<1>(L, S, trb, ring, lck, lane, ovf);
-    case 2: return nuss_wave_reg<2>(L, S, trb, ring, lck, lane, ovf);
-    case 3: return nuss_wave_reg<3>(L, S, trb, ring, lck, lane, ovf);
-    case 4: return nuss_wave_reg<4>(L, S, trb, ring, lck, lane, ovf);
-    case 5: return nuss_wave_reg<5>(L, S, trb, ring, lck, lane, ovf);
-    case 6: return nuss_wave_reg<6>(L, S, trb, ring, lck, lane, ovf);
-    case 7: return nuss_wave_reg<7>(L, S, trb, ring, lck, lane, ovf);
-    default: return nuss_wave_reg<8>(L, S, trb, ring, lck, lane, ovf);
+    case 1: return nuss_wave_reg<1, TRG>(L, S, trb, trbg, ring, lck, lane, ovf);
+    case 2: return nuss_wave_reg<2, TRG>(L, S, trb, trbg, ring, lck, lane, ovf);
+    case 3: return nuss_wave_reg<3, TRG>(L, S, trb, trbg, ring, lck, lane, ovf);
+    case 4: return nuss_wave_reg<4, TRG>(L, S, trb, trbg, ring, lck, lane, ovf);
+    case 5: return nuss_wave_reg<5, TRG>(L, S, trb, trbg, ring, lck, lane, ovf);
+    case 6: return nuss_wave_reg<6, TRG>(L, S, trb, trbg, ring, lck, lane, ovf);
+    case 7: return nuss_wave_reg<7, TRG>(L, S, trb, trbg, ring, lck, lane, ovf);
+    default: return nuss_wave_reg<8, TRG>(L, S, trb, trbg, ring, lck, lane, ovf);
   }
+}
+// trb (LDS nibbles) when the fold was granted room for them, else the byte table trbg in HBM
+__device__ __forceinline__ float nuss_wave_fast(uint32_t W, uint32_t L, const float* S, uint32_t* trb, uint8_t* trbg, float* ring, uint32_t* lck, int lane, bool* ovf) {
+  return trb ? nuss_wave_fast_t<false>(W, L, S, trb, trbg, ring, lck, lane, ovf) : nuss_wave_fast_t<true>(W, L, S, trb, trbg, ring, lck, lane, ovf);
 }
 
 // traceback of nuss_wave_reg's codes (see nuss_traceback_b for the walk)
@@ -483,15 +497,20 @@ __device__ __noinline__ float nuss_wave_fast(uint32_t W, uint32_t L, const float
 // of runs: stretches of code 1 (i+1), of code 2 (j-1) and stacks of code 3 (i+1, j-1).  The lanes read the
 // next 64 cells along the current direction at once and a ballot finds where the run ends, so a run costs
 // two LDS round trips instead of two per cell.  Bifurcations park their left half on an LDS stack.
-__device__ void nuss_traceback_fast(uint32_t L, uint32_t* trb_, uint32_t* lck_, uint32_t* ss_, uint32_t* stack_, int lane) {
+__device__ void nuss_traceback_fast(uint32_t L, uint32_t* trb_, const uint8_t* trbg_, uint32_t* lck_, uint32_t* ss_, uint32_t* stack_, int lane) {
   DD_LDS const uint32_t* trb = (DD_LDS const uint32_t*)trb_;
+  DD_GLB const uint8_t* trbg = (DD_GLB const uint8_t*)trbg_;
+  const bool in_lds = trb_ != nullptr;
+  if (!in_lds) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the DP's code stores have reached L2
   DD_LDS const uint32_t* lck = (DD_LDS const uint32_t*)lck_;
   DD_LDS uint32_t* stack = (DD_LDS uint32_t*)stack_;
   DD_GLB uint32_t* ss = (DD_GLB uint32_t*)ss_;
   auto code = [&](int i, int j) -> uint32_t {  // traceback code of cell (i, j), 0 outside the triangle j > i
     if (!(i >= 0 && j > i && j < (int)L)) return 0u;
     const uint32_t q = (uint32_t)tri_index(L, (uint32_t)i, (uint32_t)j);
-    return (trb[q >> 3] >> ((q & 7u) * 4)) & 15u;
+    // the byte table was written by other lanes: read it at L2 (agent scope), past this CU's vector cache
+    return in_lds ? (trb[q >> 3] >> ((q & 7u) * 4)) & 15u
+                  : (uint32_t)__hip_atomic_load((const uint8_t*)trbg_ + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   uint32_t sp = 0;
   int i = 0, j = (int)L - 1;
@@ -1110,14 +1129,14 @@ __device__ __noinline__ void dd_folder(const dd_node& nd, const dd_params& prm, 
   uint8_t* trb_g = isx ? nd.trb_x : nd.trb_y;
   uint32_t* trk = isx ? nd.trk_x : nd.trk_y;
   uint32_t* ss = isx ? nd.x : nd.y;
-  float* P = (float*)s_dd;
-  float* Sb = P + W * 64;
-  uint32_t* cc = (uint32_t*)(Sb + W * 64);
-  uint32_t* w = cc + L;
   const uint32_t nw = (uint32_t)(((size_t)L * (L + 1) / 2 + 7) / 8);
   uint32_t *trbp = nullptr, *lck = nullptr;
   float* ring = nullptr;
-  if (nd.fold_fast & (isx ? 1u : 2u)) { trbp = w; w += nw; ring = (float*)w; w += 64 * L; lck = w; }
+  float* P = (float*)s_dd;  // buffers of the HBM-table form: inside the ring when there is one (dd_ring_words)
+  if (nd.fold_fast & (isx ? 1u : 2u)) { trbp = (uint32_t*)s_dd; ring = (float*)(trbp + nw); lck = (uint32_t*)(ring + dd_ring_words(L)); P = ring; }
+  else if (nd.fold_fast & (isx ? 4u : 8u)) { ring = (float*)s_dd; lck = (uint32_t*)(ring + dd_ring_words(L)); P = ring; }  // codes in HBM
+  float* Sb = P + W * 64;
+  uint32_t* cc = (uint32_t*)(Sb + W * 64);
   for (uint32_t it = t_first;; ++it) {
     if (tid == 0) {
       uint32_t g = 0, spins = 0;
@@ -1132,10 +1151,10 @@ __device__ __noinline__ void dd_folder(const dd_node& nd, const dd_params& prm, 
     if (wave == 0) {
       bool slow = true;
       float sc = 0.0f;
-      if (trbp && W <= DD_WREG) sc = nuss_wave_fast(W, L, S, trbp, ring, lck, lane, &slow);
+      if (ring && W <= DD_WREG) sc = nuss_wave_fast(W, L, S, trbp, trb_g, ring, lck, lane, &slow);
       if (slow) sc = nuss_wave(L, S, ws, trb_g, trk, P, Sb, cc, lane);
       if (lane == 0) s_fscore = sc;
-      if (!slow) nuss_traceback_fast(L, trbp, lck, ss, (uint32_t*)P, lane);
+      if (!slow) nuss_traceback_fast(L, trbp, trb_g, lck, ss, (uint32_t*)P, lane);
       else if (lane == 0) nuss_traceback_b(L, trb_g, trk, ss, (uint32_t*)P);
     }
     __syncthreads();
@@ -1179,16 +1198,20 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
   // traceback tables fit (nd.lds_flags, decided by the host): bit 0 alignment, bit 1 x, bit 2 y
   extern __shared__ unsigned char s_dd[];
   const uint32_t Wx = (L1 + 63) / 64, Wy = (L2 + 63) / 64, Wz = (L2 + 64) / 64;
-  float* Px = (float*)s_dd;
-  float* Sbx = Px + Wx * 64;
-  float* Py = Sbx + Wx * 64;
-  float* Sby = Py + Wy * 64;
-  float* Pz = Sby + Wy * 64;
+  float* Pz = (float*)s_dd;
   float* Pbz = Pz + Wz * 64;
   float* Qbz = Pbz + Wz * 64;
-  uint32_t* ccx = (uint32_t*)(Qbz + Wz * 64);
-  uint32_t* ccy = ccx + L1;
-  unsigned char* lds_tail = (unsigned char*)(ccy + L2);
+  // previous-row buffers and candidate counters of the HBM-table folding forms: room of their own only when the
+  // fold has no on-chip region (otherwise they borrow its ring, see dd_ring_words) and this workgroup folds at all
+  const bool fastx = (nd.lds_flags & (2u | 8u)) != 0, fasty = (nd.lds_flags & (4u | 8u)) != 0;
+  float *Px = nullptr, *Py = nullptr;
+  unsigned char* lds_tail;
+  {
+    float* q = Qbz + Wz * 64;
+    if (!split && !fastx) { Px = q; q += dd_slow_words(L1); }
+    if (!split && !fasty) { Py = q; q += dd_slow_words(L2); }
+    lds_tail = (unsigned char*)q;
+  }
   // bit 0: packed alignment traceback; bit 1 / bit 2: the fast form of the x / y folding DP
   // (in-flight rows, candidate lists and packed traceback codes)
   const uint32_t nzw = (uint32_t)(((size_t)(L1 + 1) * (L2 + 1) + 15) / 16), nxw = (uint32_t)(((size_t)L1 * (L1 + 1) / 2 + 7) / 8),
@@ -1199,15 +1222,21 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
   {
     uint32_t* w = (uint32_t*)lds_tail;
     if (nd.lds_flags & 1) { trzp = w; w += nzw; }
-    if (nd.lds_flags & 2) { trxp = w; w += nxw; ringx = (float*)w; w += 64 * L1; lckx = w; w += DD_CAP * L1; }
-    if (nd.lds_flags & 4) { tryp = w; w += nyw; ringy = (float*)w; w += 64 * L2; lcky = w; w += DD_CAP * L2; }
+    if (nd.lds_flags & 2) { trxp = w; w += nxw; ringx = (float*)w; w += dd_ring_words(L1); lckx = w; w += DD_CAP * L1; }
+    if (nd.lds_flags & 4) { tryp = w; w += nyw; ringy = (float*)w; w += dd_ring_words(L2); lcky = w; w += DD_CAP * L2; }
     if (nd.lds_flags & 8) {  // one region for both folding DPs, used by x and then by y
-      const uint32_t Lm = L1 > L2 ? L1 : L2;
-      trxp = tryp = w; w += nxw > nyw ? nxw : nyw;
-      ringx = ringy = (float*)w; w += 64 * Lm;
+      const uint32_t Lm = L1 > L2 ? L1 : L2, rw1 = dd_ring_words(L1), rw2 = dd_ring_words(L2);
+      if (!(nd.lds_flags & 16)) { trxp = tryp = w; w += nxw > nyw ? nxw : nyw; }  // bit 4: the codes go to HBM instead
+      ringx = ringy = (float*)w; w += rw1 > rw2 ? rw1 : rw2;
       lckx = lcky = w; w += DD_CAP * Lm;
     }
+    if (fastx) Px = ringx;
+    if (fasty) Py = ringy;
   }
+  float* Sbx = Px + Wx * 64;
+  float* Sby = Py + Wy * 64;
+  uint32_t* ccx = (uint32_t*)(Sbx + Wx * 64);
+  uint32_t* ccy = (uint32_t*)(Sby + Wy * 64);
   const bool shared_xy = (nd.lds_flags & 8) != 0;
   __shared__ uint32_t s_x_done;  // iteration whose x folding (DP + traceback) has released the shared region
   if (tid == 0) s_x_done = 0xFFFFFFFFu;
@@ -1248,12 +1277,12 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
     } else if (wave == 0) {
       bool slow = true;
       float sc = 0.0f;
-      if (trxp && Wx <= DD_WREG) sc = nuss_wave_fast(Wx, L1, nd.s_x, trxp, ringx, lckx, lane, &slow);
+      if (ringx && Wx <= DD_WREG) sc = nuss_wave_fast(Wx, L1, nd.s_x, trxp, nd.trb_x, ringx, lckx, lane, &slow);
       if (slow && lane == 0 && prm.stamps) nd.info[4] += 1;  // iterations that took the slower form
       if (slow) sc = nuss_wave(L1, nd.s_x, nd.wx, nd.trb_x, nd.trk_x, Px, Sbx, ccx, lane);
       DD_TICK(0);
       if (lane == 0) s_score[0] = sc;
-      if (!slow) nuss_traceback_fast(L1, trxp, lckx, nd.x, (uint32_t*)Px, lane);
+      if (!slow) nuss_traceback_fast(L1, trxp, nd.trb_x, lckx, nd.x, (uint32_t*)Px, lane);
       else if (lane == 0) nuss_traceback_b(L1, nd.trb_x, nd.trk_x, nd.x, (uint32_t*)Px);
       DD_TICK(1);
       if (shared_xy) {  // hand the region to the y folding
@@ -1265,14 +1294,14 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
       float sc = 0.0f;
       if (shared_xy) {
         while (__hip_atomic_load(&s_x_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t) __builtin_amdgcn_s_sleep(8);
-        for (uint32_t e = (uint32_t)lane; e < nyw; e += 64) tryp[e] = 0;
+        if (tryp) for (uint32_t e = (uint32_t)lane; e < nyw; e += 64) tryp[e] = 0;
         wave_lds_fence();
       }
-      if (tryp && Wy <= DD_WREG) sc = nuss_wave_fast(Wy, L2, nd.s_y, tryp, ringy, lcky, lane, &slow);
+      if (ringy && Wy <= DD_WREG) sc = nuss_wave_fast(Wy, L2, nd.s_y, tryp, nd.trb_y, ringy, lcky, lane, &slow);
       if (slow && lane == 0 && prm.stamps) nd.info[5] += 1;
       if (slow) sc = nuss_wave(L2, nd.s_y, nd.wy, nd.trb_y, nd.trk_y, Py, Sby, ccy, lane);
       if (lane == 0) s_score[1] = sc;
-      if (!slow) nuss_traceback_fast(L2, tryp, lcky, nd.y, (uint32_t*)Py, lane);
+      if (!slow) nuss_traceback_fast(L2, tryp, nd.trb_y, lcky, nd.y, (uint32_t*)Py, lane);
       else if (lane == 0) nuss_traceback_b(L2, nd.trb_y, nd.trk_y, nd.y, (uint32_t*)Py);
     }
     if (wave == 2) {

@@ -149,3 +149,20 @@ def test_split_mode_and_shared_region(oracle, monkeypatch):
     monkeypatch.setenv("DAFS_HIP_DD_SPLIT", "0")  # the same run with the foldings kept inside the leader's workgroup
     ref = pipeline.run(names, seqs, bp=bp, t_max=40, level_sync=True)
     assert ref.output == want and ref.dd_log == got.dd_log
+
+
+def test_fast_folding_with_codes_in_hbm(oracle, monkeypatch):
+    """Alignments of ~430-510 columns: the nibble table of the traceback no longer fits LDS beside the rows in
+    flight, so the register form of the folding DP writes its codes to HBM (one byte per cell).  Checked in the
+    split placement (a workgroup per folding) and inside the leader's workgroup (one shared region, x then y)."""
+    from dafs_amd import pipeline
+    from test_pct_gpu import random_bp
+    recs = synth.family_set(4, 455, seed=43)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    assert 420 < min(len(s) for s in seqs) and max(len(s) for s in seqs) <= 512
+    bp = random_bp(seqs, 43, density=0.006)
+    want, (it, vi), got = _run_both(oracle, names, seqs, bp, t_max=25)
+    assert got.output == want
+    monkeypatch.setenv("DAFS_HIP_DD_SPLIT", "0")
+    ref = pipeline.run(names, seqs, bp=bp, t_max=25, level_sync=True)
+    assert ref.output == want and ref.dd_log == got.dd_log
