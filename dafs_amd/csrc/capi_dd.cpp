@@ -220,7 +220,7 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
       carve_nuss(cv, L2, nd.wy);
       nd.dp_z = cv.take<float>(T); nd.tr_z = cv.take<uint8_t>(T);
       nd.trb_x = cv.take<uint8_t>(XX / 2 + L1 + 16); nd.trb_y = cv.take<uint8_t>(YY / 2 + L2 + 16);
-      nd.s_x = cv.take<float>(((size_t)L1 + 63) * ((L1 + 63) / 64) * 64); nd.s_y = cv.take<float>(((size_t)L2 + 63) * ((L2 + 63) / 64) * 64);
+      nd.s_x = cv.take<float>(((size_t)L1 + 63) * dd_fold_cols(L1) * 64); nd.s_y = cv.take<float>(((size_t)L2 + 63) * dd_fold_cols(L2) * 64);  // steps x columns per lane x 64 lanes
       nd.pz_s = cv.take<float>(((size_t)L1 + 63) * ((L2 + 64) / 64) * 64); nd.qz_s = cv.take<float>(((size_t)L1 + 63) * ((L2 + 64) / 64) * 64);
       nd.trk_x = nd.wx.tr; nd.trk_y = nd.wy.tr;  // the L*L uint32 tables double as bifurcation codes
       {  // LDS plan (mirrors the carving at the top of k_dd_solve / dd_folder)
@@ -234,11 +234,12 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
         const size_t shared = (std::max(nib(L1), nib(L2)) + std::max(dd_ring_words(L1), dd_ring_words(L2)) + (size_t)DD_CAP * Lm) * 4;
         const size_t shared_g = (std::max(dd_ring_words(L1), dd_ring_words(L2)) + (size_t)DD_CAP * Lm) * 4;
         auto fast_g = [&](uint32_t L) { return ((size_t)dd_ring_words(L) + (size_t)DD_CAP * L) * 4; };  // traceback codes in HBM
+        auto wide_ok = [](uint32_t L, uint32_t cols) { return dd_fold_cols(L) <= cols; };  // a register form exists for this width
         size_t used = base_z;
         nd.lds_flags = 0;
         if (used + fast(L1) + fast(L2) <= kDdLdsBudget) { used += fast(L1) + fast(L2); nd.lds_flags = 2u | 4u; }  // x and y side by side
-        else if (Lm <= 64 * DD_WREG && used + shared <= kDdLdsBudget) { used += shared; nd.lds_flags = 8u; }      // one region, x then y
-        else if (Lm <= 64 * DD_WREG && used + shared_g <= kDdLdsBudget) { used += shared_g; nd.lds_flags = 8u | 16u; }  // the same, codes in HBM
+        else if (wide_ok(L1, DD_WREG) && wide_ok(L2, DD_WREG) && used + shared <= kDdLdsBudget) { used += shared; nd.lds_flags = 8u; }      // one region, x then y
+        else if (wide_ok(L1, DD_WFOLD) && wide_ok(L2, DD_WFOLD) && used + shared_g <= kDdLdsBudget) { used += shared_g; nd.lds_flags = 8u | 16u; }  // the same, codes in HBM
         else used += slow_x + slow_y;
         if (used + need_z <= kDdLdsBudget) { used += need_z; nd.lds_flags |= 1u; }
         lds[b] = used;
@@ -251,8 +252,8 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
           const uint32_t Ls[2] = {L1, L2};
           for (int r = 0; r < 2; ++r) {
             const uint32_t L = Ls[r];
-            if (L <= 64 * DD_WREG && fast(L) <= kDdLdsBudget) { nd.fold_fast |= 1u << r; worst = std::max(worst, fast(L)); }
-            else if (L <= 64 * DD_WREG && fast_g(L) <= kDdLdsBudget) { nd.fold_fast |= 4u << r; worst = std::max(worst, fast_g(L)); }
+            if (wide_ok(L, DD_WREG) && fast(L) <= kDdLdsBudget) { nd.fold_fast |= 1u << r; worst = std::max(worst, fast(L)); }
+            else if (wide_ok(L, DD_WFOLD) && fast_g(L) <= kDdLdsBudget) { nd.fold_fast |= 4u << r; worst = std::max(worst, fast_g(L)); }
             else worst = std::max(worst, (size_t)dd_slow_words(L) * 4);
           }
           if (nd.fold_fast) split_lds[b] = std::max(worst, used);

@@ -66,12 +66,16 @@ int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_
 int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, uint32_t* d_ncbp, hipStream_t st);  // d_ncbp[b]: consensus pairs of node b
 int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st);
 #define DD_LMAX 4096  // longest child alignment the node kernels take (64 lanes x 64 columns; LDS row buffers)
-#define DD_WREG 8     // widest lane (columns) of the register-resident DP forms
+#define DD_WREG 8     // widest lane (columns) of the register-resident alignment DP, and of the folding DP with its codes in LDS
+#define DD_WFOLD 16   // widest lane of the register-resident folding DP (codes in HBM beyond DD_WREG)
 #define DD_CAP 4  // candidates per column kept in LDS by the fast folding DP
 // LDS words of the in-flight rows of a fast folding DP: one row of L values per active lane (the lanes own
 // ceil(L/64) columns each, so ceil(L / that) of them are at work).  The previous-row buffers and candidate counters of
 // the HBM-table form borrow the same words when that form has to run (the ring is idle then), hence the floor.
-static inline __host__ __device__ uint32_t dd_fold_cols(uint32_t L) { return (L + 63) / 64; }
+// Columns per lane of the folding wave DPs.  Up to 512 columns all 64 lanes are used; from there to 768 only 48, so
+// that the rows in flight (one per lane at work, L values each) still fit LDS and the register form can run with up
+// to DD_WFOLD columns per lane; wider alignments use 64 lanes again and the HBM-table form.
+static inline __host__ __device__ uint32_t dd_fold_cols(uint32_t L) { return (L > 512 && L <= 768) ? (L + 47) / 48 : (L + 63) / 64; }
 static inline __host__ __device__ uint32_t dd_ring_rows(uint32_t L) { const uint32_t W = dd_fold_cols(L); return W ? (L + W - 1) / W : 0; }
 static inline __host__ __device__ uint32_t dd_slow_words(uint32_t L) { return 2 * dd_fold_cols(L) * 64 + L; }
 static inline __host__ __device__ uint32_t dd_ring_words(uint32_t L) {

@@ -33,6 +33,8 @@ namespace dafs {
 #define DD_CUTOFF 0.01f  // reference CUTOFF (double 0.01): for float v, v > 0.01 <=> v > 0.01f
 #define DD_NONE 0xFFFFFFFFu
 #define DD_THREADS 512
+// k_dd_solve: four wavefronts (x, y, z, housekeeping), one per SIMD, so each may use the whole register file
+#define DD_SOLVE_THREADS 256
 
 // ------------------------------------------------------------------------------------------
 // SparseNussinov
@@ -255,7 +257,7 @@ __device__ __forceinline__ size_t tri_index(uint32_t L, uint32_t i, uint32_t j) 
 // so no global-memory latency sits on the per-cell dependency chain.
 __device__ float nuss_wave(uint32_t L, const float* __restrict__ S, const nuss_ws& ws, uint8_t* trb, uint32_t* trk, float* P, float* Sb,
                            uint32_t* cc, int lane) {
-  const uint32_t W = (L + 63) / 64;
+  const uint32_t W = dd_fold_cols(L);
   for (uint32_t c = 0; c < W; ++c) {
     P[c * 64 + lane] = 0.0f;
     Sb[c * 64 + lane] = 0.0f;
@@ -484,8 +486,24 @@ __device__ __noinline__ float nuss_wave_fast_t(uint32_t W, uint32_t L, const flo
     case 5: return nuss_wave_reg<5, TRG>(L, S, trb, trbg, ring, lck, lane, ovf);
     case 6: return nuss_wave_reg<6, TRG>(L, S, trb, trbg, ring, lck, lane, ovf);
     case 7: return nuss_wave_reg<7, TRG>(L, S, trb, trbg, ring, lck, lane, ovf);
-    default: return nuss_wave_reg<8, TRG>(L, S, trb, trbg, ring, lck, lane, ovf);
+    case 8: return nuss_wave_reg<8, TRG>(L, S, trb, trbg, ring, lck, lane, ovf);
+    default: break;
   }
+  if (TRG) {  // 9-16 columns per lane: alignments of 513-768 columns, whose codes never fit LDS
+    switch (W) {
+      case 9: return nuss_wave_reg<9, true>(L, S, trb, trbg, ring, lck, lane, ovf);
+      case 10: return nuss_wave_reg<10, true>(L, S, trb, trbg, ring, lck, lane, ovf);
+      case 11: return nuss_wave_reg<11, true>(L, S, trb, trbg, ring, lck, lane, ovf);
+      case 12: return nuss_wave_reg<12, true>(L, S, trb, trbg, ring, lck, lane, ovf);
+      case 13: return nuss_wave_reg<13, true>(L, S, trb, trbg, ring, lck, lane, ovf);
+      case 14: return nuss_wave_reg<14, true>(L, S, trb, trbg, ring, lck, lane, ovf);
+      case 15: return nuss_wave_reg<15, true>(L, S, trb, trbg, ring, lck, lane, ovf);
+      case 16: return nuss_wave_reg<16, true>(L, S, trb, trbg, ring, lck, lane, ovf);
+      default: break;
+    }
+  }
+  *ovf = true;  // no register form for this width: the caller falls back to nuss_wave
+  return 0.0f;
 }
 // trb (LDS nibbles) when the fold was granted room for them, else the byte table trbg in HBM
 __device__ __forceinline__ float nuss_wave_fast(uint32_t W, uint32_t L, const float* S, uint32_t* trb, uint8_t* trbg, float* ring, uint32_t* lck, int lane, bool* ovf) {
@@ -499,7 +517,6 @@ __device__ __forceinline__ float nuss_wave_fast(uint32_t W, uint32_t L, const fl
 // two LDS round trips instead of two per cell.  Bifurcations park their left half on an LDS stack.
 __device__ void nuss_traceback_fast(uint32_t L, uint32_t* trb_, const uint8_t* trbg_, uint32_t* lck_, uint32_t* ss_, uint32_t* stack_, int lane) {
   DD_LDS const uint32_t* trb = (DD_LDS const uint32_t*)trb_;
-  DD_GLB const uint8_t* trbg = (DD_GLB const uint8_t*)trbg_;
   const bool in_lds = trb_ != nullptr;
   if (!in_lds) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the DP's code stores have reached L2
   DD_LDS const uint32_t* lck = (DD_LDS const uint32_t*)lck_;
@@ -639,7 +656,7 @@ __device__ __forceinline__ size_t nw_skew(uint32_t W, uint32_t i, uint32_t k) { 
 }
 // all threads: S = w*(p-th)-q (nussinov.cpp:236); the association is the reference's
 __device__ void dd_fill_scores(uint32_t L, const float* __restrict__ p, const float* __restrict__ q, float w, float th, float* S) {
-  const uint32_t W = (L + 63) / 64;
+  const uint32_t W = dd_fold_cols(L);
   for (size_t c = threadIdx.x; c < (size_t)L * L; c += blockDim.x) {
     const uint32_t i = (uint32_t)(c / L), j = (uint32_t)(c - (size_t)i * L);
     S[nuss_skew(L, W, i, j)] = j >= i + 3 ? w * (p[c] - th) - q[c] : 0.0f;  // a pair spans at least three (nussinov.cpp:236 is inside the span loop)
@@ -1123,7 +1140,7 @@ __device__ __noinline__ void dd_folder(const dd_node& nd, const dd_params& prm, 
   const int wave = (int)(tid >> 6), lane = (int)(tid & 63);
   const bool isx = role == 1;
   const uint32_t L = isx ? nd.L1 : nd.L2;
-  const uint32_t W = (L + 63) / 64;
+  const uint32_t W = dd_fold_cols(L);
   const float* S = isx ? nd.s_x : nd.s_y;
   const nuss_ws& ws = isx ? nd.wx : nd.wy;
   uint8_t* trb_g = isx ? nd.trb_x : nd.trb_y;
@@ -1151,7 +1168,7 @@ __device__ __noinline__ void dd_folder(const dd_node& nd, const dd_params& prm, 
     if (wave == 0) {
       bool slow = true;
       float sc = 0.0f;
-      if (ring && W <= DD_WREG) sc = nuss_wave_fast(W, L, S, trbp, trb_g, ring, lck, lane, &slow);
+      if (ring && W <= DD_WFOLD) sc = nuss_wave_fast(W, L, S, trbp, trb_g, ring, lck, lane, &slow);
       if (slow) sc = nuss_wave(L, S, ws, trb_g, trk, P, Sb, cc, lane);
       if (lane == 0) s_fscore = sc;
       if (!slow) nuss_traceback_fast(L, trbp, trb_g, lck, ss, (uint32_t*)P, lane);
@@ -1168,7 +1185,7 @@ __device__ __noinline__ void dd_folder(const dd_node& nd, const dd_params& prm, 
 // ------------------------------------------------------------------------------------------
 // the subgradient loop, dafs.cpp:1066-1294
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, dd_params prm, uint32_t* paused_out) {
+__global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* nodes, dd_params prm, uint32_t* paused_out) {
   const dd_node nd = nodes[blockIdx.x];
   if (blockIdx.y != 0) {  // folding workgroups of a split node
     if (nd.split) dd_folder(nd, prm, blockIdx.y, nd.info[6] != 0 ? nd.info[1] : 0u);
@@ -1197,7 +1214,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
   // dynamic LDS: previous-row buffers and candidate counters of the three wave DPs, then whichever
   // traceback tables fit (nd.lds_flags, decided by the host): bit 0 alignment, bit 1 x, bit 2 y
   extern __shared__ unsigned char s_dd[];
-  const uint32_t Wx = (L1 + 63) / 64, Wy = (L2 + 63) / 64, Wz = (L2 + 64) / 64;
+  const uint32_t Wx = dd_fold_cols(L1), Wy = dd_fold_cols(L2), Wz = (L2 + 64) / 64;
   float* Pz = (float*)s_dd;
   float* Pbz = Pz + Wz * 64;
   float* Qbz = Pbz + Wz * 64;
@@ -1277,7 +1294,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
     } else if (wave == 0) {
       bool slow = true;
       float sc = 0.0f;
-      if (ringx && Wx <= DD_WREG) sc = nuss_wave_fast(Wx, L1, nd.s_x, trxp, nd.trb_x, ringx, lckx, lane, &slow);
+      if (ringx && Wx <= DD_WFOLD) sc = nuss_wave_fast(Wx, L1, nd.s_x, trxp, nd.trb_x, ringx, lckx, lane, &slow);
       if (slow && lane == 0 && prm.stamps) nd.info[4] += 1;  // iterations that took the slower form
       if (slow) sc = nuss_wave(L1, nd.s_x, nd.wx, nd.trb_x, nd.trk_x, Px, Sbx, ccx, lane);
       DD_TICK(0);
@@ -1297,7 +1314,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_solve(const dd_node* nodes, d
         if (tryp) for (uint32_t e = (uint32_t)lane; e < nyw; e += 64) tryp[e] = 0;
         wave_lds_fence();
       }
-      if (ringy && Wy <= DD_WREG) sc = nuss_wave_fast(Wy, L2, nd.s_y, tryp, nd.trb_y, ringy, lcky, lane, &slow);
+      if (ringy && Wy <= DD_WFOLD) sc = nuss_wave_fast(Wy, L2, nd.s_y, tryp, nd.trb_y, ringy, lcky, lane, &slow);
       if (slow && lane == 0 && prm.stamps) nd.info[5] += 1;
       if (slow) sc = nuss_wave(L2, nd.s_y, nd.wy, nd.trb_y, nd.trk_y, Py, Sby, ccy, lane);
       if (lane == 0) s_score[1] = sc;
@@ -1542,7 +1559,7 @@ int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size
   }
   if (lds_bytes > kDdLdsBudget) return DAFS_HIP_EINVAL;
   // split mode needs the three workgroups of a node on the machine together: the caller keeps 3 * nnodes within the CU count
-  hipLaunchKernelGGL(k_dd_solve, dim3(nnodes, split ? 3 : 1), dim3(DD_THREADS), lds_bytes, st, d_nodes, prm, d_paused);
+  hipLaunchKernelGGL(k_dd_solve, dim3(nnodes, split ? 3 : 1), dim3(DD_SOLVE_THREADS), lds_bytes, st, d_nodes, prm, d_paused);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 int nussinov_launch(uint32_t L, const float* p, const float* q, float w, float th, nuss_ws ws, uint32_t* ss, float* score, hipStream_t st) {

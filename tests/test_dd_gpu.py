@@ -151,15 +151,17 @@ def test_split_mode_and_shared_region(oracle, monkeypatch):
     assert ref.output == want and ref.dd_log == got.dd_log
 
 
-def test_fast_folding_with_codes_in_hbm(oracle, monkeypatch):
+@pytest.mark.parametrize("length", [455, 600, 700])
+def test_fast_folding_with_codes_in_hbm(oracle, monkeypatch, length):
     """Alignments of ~430-510 columns: the nibble table of the traceback no longer fits LDS beside the rows in
-    flight, so the register form of the folding DP writes its codes to HBM (one byte per cell).  Checked in the
-    split placement (a workgroup per folding) and inside the leader's workgroup (one shared region, x then y)."""
+    flight, so the register form of the folding DP writes its codes to HBM (one byte per cell); from 513 to 768
+    columns it runs on 48 lanes with up to 16 columns each.  Checked in the split placement (a workgroup per
+    folding) and inside the leader's workgroup (one shared region, x then y)."""
     from dafs_amd import pipeline
     from test_pct_gpu import random_bp
-    recs = synth.family_set(4, 455, seed=43)
+    recs = synth.family_set(4, length, seed=43)
     names, seqs = [r[0] for r in recs], [r[1] for r in recs]
-    assert 420 < min(len(s) for s in seqs) and max(len(s) for s in seqs) <= 512
+    assert 420 < min(len(s) for s in seqs) and max(len(s) for s in seqs) <= 768
     bp = random_bp(seqs, 43, density=0.006)
     want, (it, vi), got = _run_both(oracle, names, seqs, bp, t_max=25)
     assert got.output == want
