@@ -14,8 +14,9 @@
 // level barrier (capi_dd.cpp: dafs_hip_nodes_*).  Per iteration the three subproblems run on three
 // wavefronts as skewed, register-resident DPs (lane t owns W columns; the folding DPs sweep rows from the
 // bottom, the alignment DP from the top) with their inputs stored in sweep order, the rows in flight,
-// candidate split points and traceback codes in LDS, followed by their tracebacks (the folding one by the
-// whole wavefront, run by run); the multiplier update is parallel over the sparse consensus structure.
+// candidate split points and traceback codes in LDS (the codes in HBM from ~415 columns on; 48 lanes of up
+// to 16 columns from 513 to 768), followed by their tracebacks (the folding one by the whole wavefront, run
+// by run); the multiplier update is parallel over the sparse consensus structure.
 // Forms that do not fit LDS fall back to the same DPs over HBM/L2 tables (nuss_wave, nw_wave).  Float sums
 // that the reference forms sequentially (the dual value s, which steers the step size) are formed in the
 // same order: positive terms are compacted in consensus-pair order and added by one lane.
