@@ -51,7 +51,9 @@ struct cf_ctx {  // per-workgroup view
   // visit only pairable (p+1, q) instead of testing every q.
   const int* plist;
   const int* pcnt;
-  CF_LDS float* ring;    // LDS ring of the last 33 spans of FC (inside) / FCo (outside): ring[(span % 33)*(L+1) + row]; null = none
+  CF_LDS float* ring;    // LDS ring of the last 33 spans of FC (inside) / FCo (outside): ring[(span % 33)*(L+1) + row]
+  bool has_ring;         // false: no room for it (sequences beyond ~540 nt), FC/FCo are read from HBM/L2.  Kept as a flag: the
+                         // null of the LDS address space is not the generic null, a pointer test after the cast is a trap
   const cf_params* P;    // score tables (LDS copy)
   bool free;             // no constraint string: every map entry is -1 and cum is all zero, the lookups are skipped
 };
@@ -106,7 +108,7 @@ __device__ __forceinline__ bool cf_map_ok(const cf_ctx& c, int a, int q) {
   return (ma == -1 || ma == q) && (mq == -1 || mq == a);
 }
 __device__ __forceinline__ float cf_fc_load(const cf_ctx& c, const float* FC, int row, int col) {  // FC[row][col], recent spans from LDS
-  if (c.ring) return c.ring[((uint32_t)(col - row) % (uint32_t)CF_RING) * (uint32_t)(c.L + 1) + (uint32_t)row];
+  if (c.has_ring) return c.ring[((uint32_t)(col - row) % (uint32_t)CF_RING) * (uint32_t)(c.L + 1) + (uint32_t)row];
   return FC[c.off[row] + col];
 }
 
@@ -182,7 +184,7 @@ __device__ void cf_inside_cell(const cf_ctx& c, int i, int j, float* FCi, float*
     FCi[off[i] + j] = sum;
     fc = sum;
   }
-  if (c.ring) c.ring[((uint32_t)(j - i) % (uint32_t)CF_RING) * (uint32_t)(L + 1) + (uint32_t)i] = fc;
+  if (c.has_ring) c.ring[((uint32_t)(j - i) % (uint32_t)CF_RING) * (uint32_t)(L + 1) + (uint32_t)i] = fc;
   if (0 < i && i + 2 <= j && j < L) {
     float sum = CONTRA_NEG_INF;
     if (cf_allow_paired(c, i + 1, j))
@@ -256,7 +258,7 @@ __device__ void cf_outside_cell(const cf_ctx& c, int a, int b, const float* FCi,
     }
     FCo[off[a] + b] = fco;
   }
-  if (c.ring) c.ring[((uint32_t)(b - a) % (uint32_t)CF_RING) * (uint32_t)(L + 1) + (uint32_t)a] = fco;
+  if (c.has_ring) c.ring[((uint32_t)(b - a) % (uint32_t)CF_RING) * (uint32_t)(L + 1) + (uint32_t)a] = fco;
 
   // ---- FM1o[a][b]: block 2 of source (a-1,b), block 4 of sources (a,j) j = L..b+1, block 1 of source (a,b)
   float fm1o = CONTRA_NEG_INF;
@@ -333,6 +335,7 @@ __device__ float cf_posterior_cell(const cf_ctx& c, int a, int q, const float* F
 #define CF_INTS(L) (12 * ((L) + 2))
 
 __device__ void cf_bind(cf_ctx& c, int L, int* ints, float* ring, const cf_params* P) {
+  c.has_ring = ring != nullptr;
   c.ring = (CF_LDS float*)ring;
   c.L = L;
   int* s = ints;
@@ -545,7 +548,7 @@ int contrafold_launch(const cf_batch& B, uint32_t nseq, uint32_t max_len, hipStr
   const size_t ring = (size_t)CF_RING * (max_len + 1) * sizeof(float);
   const size_t budget = 100 * 1024;  // dynamic LDS (static: score tables ~11 KB)
   if (ints > budget) return DAFS_HIP_ETOOLONG;
-  const int use_ring = ints + ring <= budget;
+  const int use_ring = ints + ring <= budget && !getenv("DAFS_HIP_CF_NORING");  // the env switch is a tuning aid
   const size_t lds = ints + (use_ring ? ring : 0);
   static bool attr = false;
   if (!attr) {

@@ -48,6 +48,26 @@ def test_fuzz_vs_oracle(ctx, oracle):
         assert post.tobytes() == t._orc_fold_post(oracle, s, cons).tobytes(), cons
 
 
+def test_sequences_too_long_for_the_lds_ring(ctx, oracle, monkeypatch):
+    """Beyond ~540 nt the 33 most recent spans of FC/FCo no longer fit LDS and the single-branch terms read them
+    from HBM/L2 instead.  One sequence of that length against the oracle, and the short fuzz set with that form
+    forced (DAFS_HIP_CF_NORING)."""
+    import test_oracle_cpu as t
+    rng = np.random.default_rng(5)
+    s = "".join(rng.choice(list("ACGU"), 600))
+    post, _ = ctx.fold_posterior_dense(s)
+    assert post.tobytes() == t._orc_fold_post(oracle, s).tobytes()
+    monkeypatch.setenv("DAFS_HIP_CF_NORING", "1")
+    for k, L in enumerate([3, 9, 33, 64, 100, 181]):
+        s = "".join(rng.choice(list("ACGU" if k % 2 else "ACGUTN"), L))
+        post, _ = ctx.fold_posterior_dense(s)
+        assert post.tobytes() == t._orc_fold_post(oracle, s).tobytes(), L
+    s = "GGGAAACUUCGGUUUCCCAAGGGAAACCC"
+    cons = "((?..........?))" + "?" * (len(s) - 16)
+    post, _ = ctx.fold_posterior_dense(s, cons)
+    assert post.tobytes() == t._orc_fold_post(oracle, s, cons).tobytes()
+
+
 def test_batch_rows_vs_oracle(ctx, oracle):
     seqs = [s for _, s in synth.random_set(5, 70, seed=21)] + ["ACGU", "GGGAAACCCTTNN"]
     ctx.set_sequences(seqs)
