@@ -164,6 +164,36 @@ __device__ void cf_inside_cell(const cf_ctx& c, int i, int j, float* FCi, float*
       const int sy = c.s[p + 1], sp = c.s[p];
       if (sy == 4) continue;  // a non-ACGU symbol pairs with nothing
       const int* pl = c.plist + sy * L;
+      if (c.free) {
+        // Unconstrained sequence: the same terms in the same order, software-pipelined.  A term is a chain of
+        // dependent LDS lookups (partner q -> symbols and FC -> score tables -> the two lookups of the
+        // log-sum-exp) and the chain, not the issue rate, is what a span waits for; so the partner of the next
+        // term is fetched before this term's tables, and its symbols and FC value before this term's
+        // log-sum-exp.
+        int e = c.pcnt[sy * (L + 2) + j] - 1;
+        if (e < 0) continue;
+        int q = pl[e];
+        if (q < q_min) continue;
+        float inner = cf_fc_load(c, FCi, p + 1, q - 1);
+        int sq_ = c.s[q], sq1 = c.s[q + 1];
+        for (;;) {
+          const bool more = e >= 1;
+          const int qn = more ? pl[e - 1] : -1;
+          const float bp = 0.0f + c.P->base_pair[sy * 5 + sq_];
+          const float jb = 0.0f + c.P->helix_closing[sq_ * 5 + sy] + c.P->terminal_mismatch[((sq_ * 5 + sy) * 5 + sq1) * 5 + sp];
+          const float score = (p == i && q == j)
+                                  ? (score_helix + inner)
+                                  : (score_other + c.P->cache_single[(p - i) * 31 + (j - q)] + inner + bp + jb + cf_single_nuc(c, i, j, p, q));
+          const bool next_ok = more && qn >= q_min;
+          float inner_n = 0.0f;
+          int sqn = 4, sq1n = 4;
+          if (next_ok) { inner_n = cf_fc_load(c, FCi, p + 1, qn - 1); sqn = c.s[qn]; sq1n = c.s[qn + 1]; }
+          sum = cf_lpe(sum, score);
+          if (!next_ok) break;
+          q = qn; inner = inner_n; sq_ = sqn; sq1 = sq1n; --e;
+        }
+        continue;
+      }
       for (int e = c.pcnt[sy * (L + 2) + j] - 1; e >= 0; --e) {  // partners q of p+1, q = j downwards
         const int q = pl[e];
         if (q < q_min) break;
@@ -235,6 +265,32 @@ __device__ void cf_outside_cell(const cf_ctx& c, int a, int b, const float* FCi,
         // (p,q) / bulge-free slot handled below for i == p, and a normal source for i < p)
         const int* pl = c.plist + sy * L;
         const int lowest = (i == p) ? q + 2 : q + 1;
+        if (c.free) {
+          // unconstrained: the same sources in the same order, software-pipelined like the inside loop (the next
+          // partner before this term's tables, its FCo value and symbols before this term's log-sum-exp)
+          int e = c.pcnt[sy * (L + 2) + jmax + 1] - 1;
+          int j1 = e >= 0 ? pl[e] : 0;  // j + 1
+          if (e >= 0 && j1 >= lowest) {
+            const int si1 = c.s[i + 1];
+            float src = cf_fc_load(c, FCo, i, j1 - 1);
+            int sj1 = c.s[j1], sj = c.s[j1 - 1];
+            for (;;) {
+              const bool more = e >= 1;
+              const int jn1 = more ? pl[e - 1] : 0;
+              const int j = j1 - 1, l2 = j - q;
+              const float jb_ij = 0.0f + c.P->helix_closing[sy * 5 + sj1] + c.P->terminal_mismatch[((sy * 5 + sj1) * 5 + si1) * 5 + sj];
+              const float score_other = src + jb_ij;
+              const float term = score_other + c.P->cache_single[l1 * 31 + l2] + bp_pq + jb_qp + cf_single_nuc(c, i, j, p, q);
+              const bool next_ok = more && jn1 >= lowest;
+              float src_n = 0.0f;
+              int sjn1 = 4, sjn = 4;
+              if (next_ok) { src_n = cf_fc_load(c, FCo, i, jn1 - 1); sjn1 = c.s[jn1]; sjn = c.s[jn1 - 1]; }
+              fco = cf_lpe(fco, term);
+              if (!next_ok) break;
+              j1 = jn1; src = src_n; sj1 = sjn1; sj = sjn; --e;
+            }
+          }
+        } else
         for (int e = c.pcnt[sy * (L + 2) + jmax + 1] - 1; e >= 0; --e) {
           const int j = pl[e] - 1;
           if (j + 1 < lowest) break;
