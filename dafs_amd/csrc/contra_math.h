@@ -70,6 +70,9 @@ struct contra_tables {
   float lk[4][260];     // k3, k2, k1, k0 of the eight cubics
   float2 ecell[20];     // exp(x), -10 <= x < 0: cell g = floor(2 (x + 10))
   float ek[4][260];     // seven cubics; piece 0 (x < -9.91152) is all zeros
+  // one-lookup form for latency-bound chains (contra_lpe_t1): per cell the cubic below the limit, the cubic from the
+  // limit on, and the limit (+inf if the cell has none)
+  float4 lone[24][3];
 };
 
 __device__ __forceinline__ void contra_tables_init(contra_tables* t, int tid) {
@@ -94,6 +97,10 @@ __device__ __forceinline__ void contra_tables_init(contra_tables* t, int tid) {
       else if (lim[q] < hi) in = lim[q];
     }
     t->lcell[g] = make_float2(in, __int_as_float(base));
+    const int up = base + 1 < 8 ? base + 1 : 7;
+    t->lone[g][0] = make_float4(k[base][0], k[base][1], k[base][2], k[base][3]);
+    t->lone[g][1] = make_float4(k[up][0], k[up][1], k[up][2], k[up][3]);
+    t->lone[g][2] = make_float4(in, 0.0f, 0.0f, 0.0f);
   }
   for (int q = 0; q < 8; ++q)
     for (int c = 0; c < 4; ++c) t->lk[c][q] = k[q][c];
@@ -150,6 +157,20 @@ __device__ __forceinline__ float contra_lpe_t(const contra_tables* t, float x, f
   const float2 cl = t->lcell[g];
   const unsigned i = (unsigned)__float_as_int(cl.y) + (d >= cl.x ? 1u : 0u);
   const float r = ((t->lk[0][i] * d + t->lk[1][i]) * d + t->lk[2][i]) * d + t->lk[3][i] + lo;
+  return (lo > (float)(-2e20 / 2) && d < (float)(11.8624794162)) ? r : hi;
+}
+
+// the same through one lookup (three 16-byte reads of the cell, no dependent second read): for the folding kernel,
+// whose single-branch sums are chains of these
+__device__ __forceinline__ float contra_lpe_t1(const contra_tables* t, float x, float y) {
+  const float hi = fmaxf(x, y), lo = fminf(x, y);
+  const float d = hi - lo;
+  const unsigned g = min((unsigned)(d * 2.0f), 23u);
+  const float4 a = t->lone[g][0], b = t->lone[g][1];
+  const float lim = t->lone[g][2].x;
+  const bool upper = d >= lim;
+  const float k3 = upper ? b.x : a.x, k2 = upper ? b.y : a.y, k1 = upper ? b.z : a.z, k0 = upper ? b.w : a.w;
+  const float r = ((k3 * d + k2) * d + k1) * d + k0 + lo;
   return (lo > (float)(-2e20 / 2) && d < (float)(11.8624794162)) ? r : hi;
 }
 

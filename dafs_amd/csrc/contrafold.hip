@@ -28,7 +28,7 @@ namespace dafs {
 // select tree at the price of one more LDS round trip on the dependency chain -- the kernel is bound by the
 // instruction stream of the few wavefronts a sequence occupies (65 -> 58 ms at N=128).  Same values either way.
 __shared__ contra_tables g_cf_tab;
-__device__ __forceinline__ float cf_lpe(float x, float y) { return contra_lpe_t(&g_cf_tab, x, y); }
+__device__ __forceinline__ float cf_lpe(float x, float y) { return contra_lpe_t1(&g_cf_tab, x, y); }
 #define CF_TABLES_INIT() do { contra_tables_init(&g_cf_tab, threadIdx.x); } while (0)
 
 
