@@ -173,9 +173,9 @@ def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25
     lines = [res.tree_line, ">SS_cons", res.ss_str]
     res.rows = []
     for r in order:
-        s = seqs[sidx[r]]
-        it = iter(s)
-        row = "".join(next(it) if m else "-" for m in mask[r])
+        row_bytes = np.full(mask.shape[1], ord("-"), np.uint8)
+        row_bytes[mask[r].astype(bool)] = np.frombuffer(seqs[sidx[r]].encode("latin-1"), np.uint8)  # residues into their columns
+        row = row_bytes.tobytes().decode("latin-1")
         res.rows.append(row)
         lines += ["> " + names[sidx[r]], row]
     res.output = "\n".join(lines) + "\n"
