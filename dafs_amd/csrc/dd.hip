@@ -326,12 +326,14 @@ __device__ float nuss_wave(uint32_t L, const float* __restrict__ S, const nuss_w
   return __shfl(score, (int)((L - 1) / W));
 }
 
-// Register-resident forms for W <= DD_WREG columns per lane (W a template constant): the previous
-// row, the scores and the candidate counters of the lane's columns live in registers, so a cell
-// without candidates touches LDS only to publish its value; a cell with candidates makes two LDS
-// round trips (all candidate keys/values at once, then all dp[i][k-1] at once).
+// Register-resident forms (W columns per lane, a template constant: up to DD_WREG for the alignment DP and for
+// the folding DP with its codes in LDS, up to DD_WFOLD for the folding DP with its codes in HBM): the previous
+// row, the scores and the candidates of the lane's columns live in registers; the only LDS traffic of a cell
+// is publishing its value and code and reading the dp[i][k-1] of its column's candidates (fetched a step
+// ahead for W <= 4).
 // Address-space-qualified views: the loops below must compile to ds_* / global_* instructions, not
 // flat_* ones (a flat access waits on both counters, i.e. on the prefetch of the next step as well).
+
 // lane t receives lane t-1's value, lane 0 receives 0: one DPP move (wave_shr:1) instead of a trip through the
 // LDS crossbar (ds_bpermute), which sits on the step-to-step dependency chain of the wave DPs
 __device__ __forceinline__ float wave_shr1(float v) {
@@ -342,7 +344,7 @@ __device__ __forceinline__ float wave_shr1(float v) {
 // The loop must not contain a global store either: on gfx9 loads and stores share vmcnt and complete
 // out of order with each other, so one possible store in flight turns every wait into vmcnt(0) and
 // the prefetch of the next step is waited for at once.  Hence: traceback codes in LDS (a bifurcation
-// is recorded as 4 + its candidate slot, the split row is read back from lck), and a column that
+// is recorded as 4 + the index of its candidate, whose split row is read back from lck), and a column that
 // collects more than DD_CAP candidates raises `ovf`; the caller then repeats the DP with
 // nuss_wave, which works in global memory.
 // TRG: the traceback codes go to HBM instead (one byte per cell of the upper triangle, trbg_) for alignments whose
