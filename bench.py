@@ -253,9 +253,11 @@ def main():
         # consistency, tree, progressive DD, final structure) on the same set; not part of `value`.
         from dafs_amd import pipeline
         ctx = capi.Context(local_rank)
-        pipeline.run(names, seqs, ctx=ctx)  # warm-up on the same set: device buffers at their final size, code objects loaded
+        # skip_uncoupled_folds=False: every node runs all three subproblems of every iteration, as the reference does
+        # (the drivers' default leaves out the folding DPs of nodes that no consensus base pair couples; same output)
+        pipeline.run(names, seqs, ctx=ctx, skip_uncoupled_folds=False)  # warm-up on the same set: device buffers at their final size, code objects loaded
         t0 = time.perf_counter()
-        res = pipeline.run(names, seqs, ctx=ctx)
+        res = pipeline.run(names, seqs, ctx=ctx, skip_uncoupled_folds=False)
         wall = time.perf_counter() - t0
         its = [v[0] for v in res.dd_log.values()]
         e2e = {"wall_s": wall, "note": "second run on a warm context (buffers allocated, kernels loaded)", "flags": "-a ProbCons -s CONTRAfold --no-alifold (defaults otherwise)",

@@ -96,7 +96,7 @@ class NodeOutput(C.Structure):
 
 class DDParams(C.Structure):
     _fields_ = [("w", C.c_float), ("eta0", C.c_float), ("th_a", C.c_float), ("th_s", C.c_float),
-                ("t_max", C.c_uint32), ("force_iters", C.c_int)]
+                ("t_max", C.c_uint32), ("force_iters", C.c_int), ("skip_uncoupled_folds", C.c_int)]
 
 
 _nussinov_decode = _sig("dafs_hip_nussinov_decode", C.c_int,

@@ -152,7 +152,7 @@ int make_geom(const dafs_hip_ctx* c, uint32_t n, uint32_t L, const uint32_t* seq
 
 extern "C" void dafs_hip_dd_default_params(dafs_dd_params* p) {
   if (!p) return;
-  p->w = 4.0f; p->eta0 = 0.5f; p->th_a = 0.01f; p->th_s = 0.2f; p->t_max = 600; p->force_iters = 0;  // dafs.cpp:1612-1640
+  p->w = 4.0f; p->eta0 = 0.5f; p->th_a = 0.01f; p->th_s = 0.2f; p->t_max = 600; p->force_iters = 0; p->skip_uncoupled_folds = 0;  // dafs.cpp:1612-1640
 }
 
 namespace {
@@ -161,6 +161,7 @@ dd_params device_params(const dafs_dd_params* prm) {
   dd_params dp;
   dp.w = prm->w; dp.eta0 = prm->eta0; dp.th_a = prm->th_a; dp.th_s = prm->th_s; dp.t_max = prm->t_max; dp.force_iters = prm->force_iters;
   dp.stamps = getenv("DAFS_HIP_DD_STAMPS") ? 1 : 0;
+  dp.skip_xy = prm->skip_uncoupled_folds ? 1 : 0;
   dp.slice = 0;
   return dp;
 }

@@ -58,6 +58,7 @@ struct dd_params {
   uint32_t t_max;
   int force_iters;
   int stamps;  // accumulate per-phase timing into info[8..13] (tuning aid)
+  int skip_xy; // dafs_dd_params::skip_uncoupled_folds
   uint32_t slice;  // at most this many iterations per launch (0 = run to the end); a node that is cut short is
                    // marked paused and continues from where it stopped at the next launch
 };

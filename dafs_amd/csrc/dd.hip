@@ -1293,8 +1293,11 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
   if (prm.stamps && tid == 0) t_prev = wall_clock64();
   uint32_t ran = 0;
   bool paused = false;
+  // prm.skip_xy: a node without consensus base pairs has nothing that couples its three subproblems, and the
+  // caller has said it consumes the alignment alone (DAFS::align_alignments, dafs.cpp:896-912): no folding DPs
+  const bool fold_on = !(prm.skip_xy && ncbp == 0);
   for (t = t_first; t != prm.t_max; ++t) {
-    if (split) {
+    if (split && fold_on) {
       // every thread's multiplier updates are out (the barrier that ended the previous iteration, or the one
       // after the initial fill); one release publishes them together with the go signal
       if (tid == 0) sync_store(&nd.sync[0], t + 1);
@@ -1308,7 +1311,9 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     if (tryp && !shared_xy) for (uint32_t e = tid; e < nyw; e += nt) tryp[e] = 0;
     // the three subproblems (dafs.cpp:1091-1093) side by side, one wavefront each, DP then traceback
     __syncthreads();
-    if (split) {
+    if (!fold_on) {
+      if (tid == 0) { s_score[0] = 0.0f; s_score[1] = 0.0f; }
+    } else if (split) {
       // the folders are at work on their own CUs
     } else if (wave == 0) {
       bool slow = true;
@@ -1325,7 +1330,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
         wave_lds_fence();
         if (lane == 0) __hip_atomic_store(&s_x_done, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-    } else if (wave == 1 && !split) {
+    } else if (wave == 1) {
       bool slow = true;
       float sc = 0.0f;
       if (shared_xy) {
@@ -1359,7 +1364,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     }
     if (tid == 0) {
       s_violated = 0;
-      if (split) {  // collect the two foldings (bounded wait; a folder that never answers fails the node)
+      if (split && fold_on) {  // collect the two foldings (bounded wait; a folder that never answers fails the node)
         uint32_t spins = 0;
         while ((sync_load(&nd.sync[1]) != t + 1 || sync_load(&nd.sync[2]) != t + 1) && ++spins < DD_SPIN_LIMIT) __builtin_amdgcn_s_sleep(16);
         if (spins >= DD_SPIN_LIMIT) s_bad = 1;

@@ -475,6 +475,12 @@ int run(const Options& o) {
   dafs_hip_dd_default_params(&prm);
   prm.w = o.w; prm.eta0 = o.eta; prm.th_a = o.align_th; prm.th_s = *std::min_element(o.fold_th.begin(), o.fold_th.end());
   prm.t_max = (uint32_t)o.max_iter;
+  // The progressive loop below uses the alignment of a node and nothing else (dafs.cpp:896-912), except that the
+  // score of the root seeds the iterative refinement and -v prints every node's iteration count (:1292): without
+  // either, nodes with no consensus base pair may leave out their folding DPs
+  // (dafs_dd_params::skip_uncoupled_folds).  The refinement itself compares scores.
+  dafs_dd_params prm_prog = prm;
+  prm_prog.skip_uncoupled_folds = (o.refinement == 0 && o.verbose == 0) ? 1 : 0;
   std::vector<ALN> aln(tree.size());
   std::vector<bool> done(tree.size(), false);
   for (uint i = 0; i < N; ++i) {
@@ -513,13 +519,13 @@ int run(const Options& o) {
           j.x.resize(in[b].len1); j.y.resize(in[b].len2); j.z.resize(in[b].len1);
         }
         std::vector<uint32_t> handles(ready.size());
-        check(dafs_hip_nodes_open(ctx, (uint32_t)ready.size(), in.data(), &prm, handles.data()));
+        check(dafs_hip_nodes_open(ctx, (uint32_t)ready.size(), in.data(), &prm_prog, handles.data()));
         for (size_t b = 0; b < ready.size(); ++b) open[first + b].handle = handles[b];
       }
       std::vector<uint32_t> handles(open.size());
       std::vector<uint8_t> fin(open.size());
       for (size_t k = 0; k < open.size(); ++k) handles[k] = open[k].handle;
-      check(dafs_hip_nodes_advance(ctx, (uint32_t)open.size(), handles.data(), &prm, kSlice, fin.data()));
+      check(dafs_hip_nodes_advance(ctx, (uint32_t)open.size(), handles.data(), &prm_prog, kSlice, fin.data()));
       std::vector<Open> still;
       for (size_t k = 0; k < open.size(); ++k) {
         if (!fin[k]) { still.push_back(std::move(open[k])); continue; }

@@ -86,7 +86,7 @@ class Result:
 
 def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25, w_pct_s=0.25, th_a=0.01,
         th_s=0.2, th_s1=None, align_model=capi.ALIGN_PROBCONS, force_iters=0, timers=None, level_sync=False, slice_iters=32,
-        mp=None):
+        mp=None, skip_uncoupled_folds=True):
     """The whole run.  bp: per-sequence (rowptr, col, val) base-pairing rows (--fold-aux); None
     computes them with the device fold model.  mp: supplied matching probabilities (--align-aux), see Context.set_mp."""
     import time
@@ -127,7 +127,10 @@ def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25
     lens = [len(s) for s in seqs]
     aln = {i: (np.array([i], np.uint32), np.ones((1, lens[i]), np.uint8)) for i in range(n)}
     pending = [i for i in range(n, 2 * n - 1)]
-    prm = capi.dd_params(w=w, eta0=eta0, th_a=th_a, th_s=th_s, t_max=t_max, force_iters=force_iters)
+    # only the alignment z of a node is consumed here (DAFS::align_alignments, dafs.cpp:896-912), so nodes that have no
+    # consensus base pair to couple their subproblems need not run their two folding DPs (dafs_dd_params doc)
+    prm = capi.dd_params(w=w, eta0=eta0, th_a=th_a, th_s=th_s, t_max=t_max, force_iters=force_iters,
+                         skip_uncoupled_folds=1 if skip_uncoupled_folds else 0)
     res.dd_log = {}
     res.dd_dims = {}  # node -> (columns of the left, of the right alignment); resident-node mode only
     res.levels = 0

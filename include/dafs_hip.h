@@ -276,6 +276,10 @@ typedef struct {
   float th_s;             /* -t    default 0.2 */
   uint32_t t_max;         /* -m    default 600 */
   int force_iters;        /* bench only: ignore the violated==0 exit (never for parity runs)  */
+  int skip_uncoupled_folds; /* default 0 = solve_by_dd as it is.  1: a node with no consensus base pair (ncbp == 0:
+                             nothing couples its three subproblems, one pass, no multiplier ever moves) runs the
+                             alignment DP only; x and y come back empty and score holds the alignment part.  For
+                             callers that consume z alone, as DAFS::align_alignments does (dafs.cpp:896-912).  */
 } dafs_dd_params;
 void dafs_hip_dd_default_params(dafs_dd_params* p);
 int dafs_hip_solve_nodes(dafs_hip_ctx* ctx, uint32_t nnodes, const dafs_node_input* in, const dafs_dd_params* prm,

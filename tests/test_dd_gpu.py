@@ -71,6 +71,7 @@ def _run_both(oracle, names, seqs, bp, **kw):
     want = pl.output()
     it, vi = pl.dd_log()
     pl.close()
+    kw.setdefault("skip_uncoupled_folds", False)  # these tests compare the iteration log with the oracle's: the solver as the reference runs it
     got = pipeline.run(names, seqs, bp=bp, **kw)
     return want, (it, vi), got
 
@@ -118,7 +119,7 @@ def test_resident_nodes_equal_level_batches(oracle, slice_iters):
     names, seqs = [r[0] for r in recs], [r[1] for r in recs]
     bp = random_bp(seqs, 21, density=0.04)
     want, (it, vi), got = _run_both(oracle, names, seqs, bp, slice_iters=slice_iters)
-    ref = pipeline.run(names, seqs, bp=bp, level_sync=True)
+    ref = pipeline.run(names, seqs, bp=bp, level_sync=True, skip_uncoupled_folds=False)
     assert got.output == want == ref.output
     assert got.dd_log == ref.dd_log
     assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
@@ -147,7 +148,7 @@ def test_split_mode_and_shared_region(oracle, monkeypatch):
     want, (it, vi), got = _run_both(oracle, names, seqs, bp, t_max=40)
     assert got.output == want
     monkeypatch.setenv("DAFS_HIP_DD_SPLIT", "0")  # the same run with the foldings kept inside the leader's workgroup
-    ref = pipeline.run(names, seqs, bp=bp, t_max=40, level_sync=True)
+    ref = pipeline.run(names, seqs, bp=bp, t_max=40, level_sync=True, skip_uncoupled_folds=False)
     assert ref.output == want and ref.dd_log == got.dd_log
 
 
@@ -166,5 +167,24 @@ def test_fast_folding_with_codes_in_hbm(oracle, monkeypatch, length):
     want, (it, vi), got = _run_both(oracle, names, seqs, bp, t_max=25)
     assert got.output == want
     monkeypatch.setenv("DAFS_HIP_DD_SPLIT", "0")
-    ref = pipeline.run(names, seqs, bp=bp, t_max=25, level_sync=True)
+    ref = pipeline.run(names, seqs, bp=bp, t_max=25, level_sync=True, skip_uncoupled_folds=False)
     assert ref.output == want and ref.dd_log == got.dd_log
+
+
+def test_uncoupled_nodes_without_their_folding_dps(oracle):
+    """dafs_dd_params.skip_uncoupled_folds: a node without consensus base pairs keeps its alignment multipliers at
+    zero whatever its two foldings do, so leaving the foldings out changes the iteration log of that node and
+    nothing else -- the alignments, hence the output, are the reference's."""
+    from dafs_amd import pipeline
+    from test_pct_gpu import random_bp
+    for recs, seed in ((synth.random_set(10, 70, seed=51), 51), (synth.family_set(12, 60, seed=21), 21)):
+        names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+        bp = random_bp(seqs, seed, density=0.03)
+        want, (it, vi), full = _run_both(oracle, names, seqs, bp)
+        lean = pipeline.run(names, seqs, bp=bp, skip_uncoupled_folds=True)
+        assert full.output == want == lean.output
+        for node, (its, viol, ncbp, score) in full.dd_log.items():
+            if ncbp:  # coupled nodes are untouched
+                assert lean.dd_log[node] == (its, viol, ncbp, score)
+            else:
+                assert lean.dd_log[node][0] <= its

@@ -87,7 +87,7 @@ def test_whole_run_with_device_fold(oracle):
     ka = t.known()
     recs = oracle.fasta(os.path.join(G, "RF00005_0.fa"))
     names, seqs = [n for n, _ in recs], [s for _, s in recs]
-    got = pipeline.run(names, seqs)
+    got = pipeline.run(names, seqs, skip_uncoupled_folds=False)
     assert got.tree_line == ka["rf00005.probcons.tree"]
     assert len(got.rows[0]) == int(ka["rf00005.probcons.contrafold.columns"])
     assert got.rows[0] == ka["rf00005.probcons.contrafold.first_row"]
