@@ -241,7 +241,13 @@ __device__ bool nw_traceback_packed(uint32_t L1, uint32_t L2, const uint32_t* tr
 // skewed by lane, the boundary column travels to the next lane by shuffle.  No barriers: the three
 // subproblems of an iteration run concurrently on three wavefronts of the workgroup.
 // ------------------------------------------------------------------------------------------
+// Address-space-qualified views: the wave DPs must compile to ds_* / global_* instructions, not flat_* ones (a flat
+// access counts on both wait counters, so an LDS operand would wait for every global store and load in flight)
+#define DD_LDS __attribute__((address_space(3)))
+#define DD_GLB __attribute__((address_space(1)))
 __device__ __forceinline__ float ld_l2(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_l2g(DD_GLB const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_l2g(DD_GLB float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_l2(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ size_t tri_index(uint32_t L, uint32_t i, uint32_t j) { return (size_t)i * L - (size_t)i * (i - 1) / 2 + (j - i); }  // j >= i
 
@@ -256,8 +262,17 @@ __device__ __forceinline__ size_t tri_index(uint32_t L, uint32_t i, uint32_t j) 
 // S: pair scores w*(p-th)-q (or p-th), precomputed by the whole workgroup (dd_fill_scores).  Row i of S
 // is fetched one step ahead into registers (16 independent loads) and parked in LDS (Sb) for the next step,
 // so no global-memory latency sits on the per-cell dependency chain.
-__device__ float nuss_wave(uint32_t L, const float* __restrict__ S, const nuss_ws& ws, uint8_t* trb, uint32_t* trk, float* P, float* Sb,
-                           uint32_t* cc, int lane) {
+__device__ float nuss_wave(uint32_t L, const float* __restrict__ S_, const nuss_ws& ws, uint8_t* trb_, uint32_t* trk_, float* P_, float* Sb_,
+                           uint32_t* cc_, int lane) {
+  DD_GLB const float* S = (DD_GLB const float*)S_;
+  DD_GLB uint8_t* trb = (DD_GLB uint8_t*)trb_;
+  DD_GLB uint32_t* trk = (DD_GLB uint32_t*)trk_;
+  DD_GLB float* dpg = (DD_GLB float*)ws.dp;
+  DD_GLB uint32_t* ckg = (DD_GLB uint32_t*)ws.ck;
+  DD_GLB float* cvg = (DD_GLB float*)ws.cv;
+  DD_LDS float* P = (DD_LDS float*)P_;
+  DD_LDS float* Sb = (DD_LDS float*)Sb_;
+  DD_LDS uint32_t* cc = (DD_LDS uint32_t*)cc_;
   const uint32_t W = dd_fold_cols(L);
   for (uint32_t c = 0; c < W; ++c) {
     P[c * 64 + lane] = 0.0f;
@@ -295,19 +310,19 @@ __device__ float nuss_wave(uint32_t L, const float* __restrict__ S, const nuss_w
           const float sc = Sb[c * 64 + lane];  // nussinov.cpp:236 / :329
           if (sc > 0.0f) {
             const float cand = diag + sc;
-            ws.ck[(size_t)j * L + n] = ui;
-            ws.cv[(size_t)j * L + n] = cand;
+            ckg[(size_t)j * L + n] = ui;
+            cvg[(size_t)j * L + n] = cand;
             cc[j] = n + 1;
             if (v < cand) { v = cand; t = 3; }
           }
         }
         for (uint32_t x = 0; x < n; ++x) {
-          const uint32_t k = ws.ck[(size_t)j * L + x];
-          const float dik = (k - 1 == ui) ? 0.0f : ld_l2(&ws.dp[(size_t)ui * L + k - 1]);  // dp[i][i] = 0 is never stored
-          const float cand = dik + ws.cv[(size_t)j * L + x];
+          const uint32_t k = ckg[(size_t)j * L + x];
+          const float dik = (k - 1 == ui) ? 0.0f : ld_l2g(&dpg[(size_t)ui * L + k - 1]);  // dp[i][i] = 0 is never stored
+          const float cand = dik + cvg[(size_t)j * L + x];
           if (v < cand) { v = cand; t = k - ui + 3; }
         }
-        st_l2(&ws.dp[(size_t)ui * L + j], v);
+        st_l2g(&dpg[(size_t)ui * L + j], v);
         trb[tri_index(L, ui, j)] = (uint8_t)(t < 4 ? t : 4);
         if (t >= 4) trk[(size_t)ui * L + j] = t;
         if (ui == 0 && j == L - 1) score = v;
@@ -339,8 +354,6 @@ __device__ float nuss_wave(uint32_t L, const float* __restrict__ S, const nuss_w
 __device__ __forceinline__ float wave_shr1(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
 }
-#define DD_LDS __attribute__((address_space(3)))
-#define DD_GLB __attribute__((address_space(1)))
 // The loop must not contain a global store either: on gfx9 loads and stores share vmcnt and complete
 // out of order with each other, so one possible store in flight turns every wait into vmcnt(0) and
 // the prefetch of the next step is waited for at once.  Hence: traceback codes in LDS (a bifurcation
@@ -706,8 +719,15 @@ __device__ void nuss_traceback_b(uint32_t L, const uint8_t* trb, const uint32_t*
 // SparseNeedlemanWunsch::decode DP (needleman_wunsch.cpp:276-296) by one wavefront; row i at step
 // i-1+lane.  Cells outside the envelope hold lowest(), row 0 / column 0 hold 0.  tr must have been
 // initialised by nw_init_tr.  Returns dp[L1][L2].
-__device__ float nw_wave(uint32_t L1, uint32_t L2, const float* __restrict__ ps, const float* __restrict__ qs, float th,
-                         const uint32_t* __restrict__ env, uint8_t* tr, float* P, float* Pb, float* Qb, int lane) {
+__device__ float nw_wave(uint32_t L1, uint32_t L2, const float* __restrict__ ps_, const float* __restrict__ qs_, float th,
+                         const uint32_t* __restrict__ env_, uint8_t* tr_, float* P_, float* Pb_, float* Qb_, int lane) {
+  DD_GLB const float* ps = (DD_GLB const float*)ps_;
+  DD_GLB const float* qs = (DD_GLB const float*)qs_;
+  DD_GLB const uint32_t* env = (DD_GLB const uint32_t*)env_;
+  DD_GLB uint8_t* tr = (DD_GLB uint8_t*)tr_;
+  DD_LDS float* P = (DD_LDS float*)P_;
+  DD_LDS float* Pb = (DD_LDS float*)Pb_;
+  DD_LDS float* Qb = (DD_LDS float*)Qb_;
   const uint32_t W = (L2 + 1 + 63) / 64, T = L2 + 1;
   for (uint32_t c = 0; c < W; ++c) {
     P[c * 64 + lane] = 0.0f;  // row 0
