@@ -257,7 +257,9 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
             else if (wide_ok(L, DD_WFOLD) && fast_g(L) <= kDdLdsBudget) { nd.fold_fast |= 4u << r; worst = std::max(worst, fast_g(L)); }
             else worst = std::max(worst, (size_t)dd_slow_words(L) * 4);
           }
-          if (nd.fold_fast) split_lds[b] = std::max(worst, used);
+          // also worth it when a folding has no register form at all: its folder runs the span-ordered form on a
+          // whole workgroup, far ahead of the HBM-table wave form the leader would run for it
+          if (nd.fold_fast || !wide_ok(L1, DD_WFOLD) || !wide_ok(L2, DD_WFOLD)) split_lds[b] = std::max(worst, used);
         }
       }
       nd.env = cv.take<uint32_t>(2 * ((size_t)L1 + 1));

@@ -1204,10 +1204,21 @@ __device__ __noinline__ void dd_folder(const dd_node& nd, const dd_params& prm, 
     for (uint32_t i = tid; i < L; i += nt) ss[i] = DD_NONE;
     if (trbp) for (uint32_t e = tid; e < nw; e += nt) trbp[e] = 0;
     __syncthreads();
-    if (wave == 0) {
+    if (!ring) {
+      // No register form for this width (beyond 768 columns, or no room): the span-ordered form on all threads of
+      // the workgroup, one barrier per span -- the standalone decoder's DP, which outruns the HBM-table wave form
+      // from a few hundred columns on (2143 columns: 31 -> 8 ms).  It takes p and q as they are (no sweep-order copy).
+      const nuss_ws none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+      const float wf = prm.w * 2 * (isx ? nd.n1 : nd.n2) / (nd.n1 + nd.n2);  // dafs.cpp:1091-1092, as in k_dd_solve
+      nuss_pair_dp(L, isx ? nd.p_x : nd.p_y, isx ? nd.q_x : nd.q_y, wf, ws, 0, nullptr, nullptr, 0.0f, none, prm.th_s);
+      if (tid == 0) {
+        nuss_traceback(L, ws, ss, ws.ck);  // the candidate-key array is free again: reuse it as the stack
+        s_fscore = ws.dp[L - 1];
+      }
+    } else if (wave == 0) {
       bool slow = true;
       float sc = 0.0f;
-      if (ring && W <= DD_WFOLD) sc = nuss_wave_fast(W, L, S, trbp, trb_g, ring, lck, lane, &slow);
+      if (W <= DD_WFOLD) sc = nuss_wave_fast(W, L, S, trbp, trb_g, ring, lck, lane, &slow);
       if (slow) sc = nuss_wave(L, S, ws, trb_g, trk, P, Sb, cc, lane);
       if (lane == 0) s_fscore = sc;
       if (!slow) nuss_traceback_fast(L, trbp, trb_g, lck, ss, (uint32_t*)P, lane);
