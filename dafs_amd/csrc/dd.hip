@@ -1174,7 +1174,8 @@ __device__ __forceinline__ void sync_store(uint32_t* p, uint32_t v) { __hip_atom
 __device__ __noinline__ void dd_folder(const dd_node& nd, const dd_params& prm, uint32_t role, uint32_t t_first) {
   extern __shared__ unsigned char s_dd[];
   __shared__ float s_fscore;
-  __shared__ uint32_t s_go;
+  __shared__ uint32_t s_go, s_slow;
+  bool gave_up = false;  // the register form overflowed earlier in this launch: straight to the span-ordered form
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const int wave = (int)(tid >> 6), lane = (int)(tid & 63);
   const bool isx = role == 1;
@@ -1183,16 +1184,13 @@ __device__ __noinline__ void dd_folder(const dd_node& nd, const dd_params& prm, 
   const float* S = isx ? nd.s_x : nd.s_y;
   const nuss_ws& ws = isx ? nd.wx : nd.wy;
   uint8_t* trb_g = isx ? nd.trb_x : nd.trb_y;
-  uint32_t* trk = isx ? nd.trk_x : nd.trk_y;
   uint32_t* ss = isx ? nd.x : nd.y;
   const uint32_t nw = (uint32_t)(((size_t)L * (L + 1) / 2 + 7) / 8);
   uint32_t *trbp = nullptr, *lck = nullptr;
   float* ring = nullptr;
-  float* P = (float*)s_dd;  // buffers of the HBM-table form: inside the ring when there is one (dd_ring_words)
+  float* P = (float*)s_dd;  // traceback stack of the register form: inside its ring, which is idle by then
   if (nd.fold_fast & (isx ? 1u : 2u)) { trbp = (uint32_t*)s_dd; ring = (float*)(trbp + nw); lck = (uint32_t*)(ring + dd_ring_words(L)); P = ring; }
   else if (nd.fold_fast & (isx ? 4u : 8u)) { ring = (float*)s_dd; lck = (uint32_t*)(ring + dd_ring_words(L)); P = ring; }  // codes in HBM
-  float* Sb = P + W * 64;
-  uint32_t* cc = (uint32_t*)(Sb + W * 64);
   for (uint32_t it = t_first;; ++it) {
     if (tid == 0) {
       uint32_t g = 0, spins = 0;
@@ -1204,25 +1202,30 @@ __device__ __noinline__ void dd_folder(const dd_node& nd, const dd_params& prm, 
     for (uint32_t i = tid; i < L; i += nt) ss[i] = DD_NONE;
     if (trbp) for (uint32_t e = tid; e < nw; e += nt) trbp[e] = 0;
     __syncthreads();
-    if (!ring) {
-      // No register form for this width (beyond 768 columns, or no room): the span-ordered form on all threads of
-      // the workgroup, one barrier per span -- the standalone decoder's DP, which outruns the HBM-table wave form
-      // from a few hundred columns on (2143 columns: 31 -> 8 ms).  It takes p and q as they are (no sweep-order copy).
+    // The register form first, unless there is none for this width (beyond 768 columns, or no room) or it has
+    // already overflowed its DD_CAP candidates per column in this launch (dense inputs do so every time).
+    if (ring && !gave_up && W <= DD_WFOLD) {
+      if (wave == 0) {
+        bool slow = true;
+        const float sc = nuss_wave_fast(W, L, S, trbp, trb_g, ring, lck, lane, &slow);
+        if (!slow) nuss_traceback_fast(L, trbp, trb_g, lck, ss, (uint32_t*)P, lane);
+        if (lane == 0) { s_fscore = sc; s_slow = slow ? 1u : 0u; }
+      }
+      __syncthreads();
+      gave_up = s_slow != 0;
+    } else gave_up = true;
+    if (gave_up) {
+      // The span-ordered form on all threads of the workgroup, one barrier per span -- the standalone decoder's DP,
+      // which outruns the HBM-table wave form from a few hundred columns on (2143 columns: 31 -> 11 ms a pass).
+      // It takes p and q as they are (no sweep-order copy).
       const nuss_ws none = {nullptr, nullptr, nullptr, nullptr, nullptr};
       const float wf = prm.w * 2 * (isx ? nd.n1 : nd.n2) / (nd.n1 + nd.n2);  // dafs.cpp:1091-1092, as in k_dd_solve
+      for (uint32_t i = tid; i < L; i += nt) ss[i] = DD_NONE;  // a register-form traceback cut short may have left marks
       nuss_pair_dp(L, isx ? nd.p_x : nd.p_y, isx ? nd.q_x : nd.q_y, wf, ws, 0, nullptr, nullptr, 0.0f, none, prm.th_s);
       if (tid == 0) {
         nuss_traceback(L, ws, ss, ws.ck);  // the candidate-key array is free again: reuse it as the stack
         s_fscore = ws.dp[L - 1];
       }
-    } else if (wave == 0) {
-      bool slow = true;
-      float sc = 0.0f;
-      if (W <= DD_WFOLD) sc = nuss_wave_fast(W, L, S, trbp, trb_g, ring, lck, lane, &slow);
-      if (slow) sc = nuss_wave(L, S, ws, trb_g, trk, P, Sb, cc, lane);
-      if (lane == 0) s_fscore = sc;
-      if (!slow) nuss_traceback_fast(L, trbp, trb_g, lck, ss, (uint32_t*)P, lane);
-      else if (lane == 0) nuss_traceback_b(L, trb_g, trk, ss, (uint32_t*)P);
     }
     __syncthreads();
     if (tid == 0) {
