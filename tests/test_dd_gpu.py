@@ -188,3 +188,21 @@ def test_uncoupled_nodes_without_their_folding_dps(oracle):
                 assert lean.dd_log[node] == (its, viol, ncbp, score)
             else:
                 assert lean.dd_log[node][0] <= its
+
+
+def test_dense_base_pairs_overflow_the_register_form(oracle, monkeypatch):
+    """With dense base-pair input a column collects more than DD_CAP candidate split points, the register form of the
+    folding DP gives up and the result comes from the fallback: in a split launch the span-ordered form on the
+    folder's whole workgroup (and no further register attempts in that launch), inside the leader's workgroup the
+    wave form over HBM tables.  Both placements against the oracle."""
+    from dafs_amd import pipeline
+    from test_pct_gpu import random_bp
+    recs = synth.family_set(4, 260, seed=61)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    bp = random_bp(seqs, 61, density=0.04)
+    want, (it, vi), got = _run_both(oracle, names, seqs, bp, t_max=12, slice_iters=5)
+    assert got.output == want
+    assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
+    monkeypatch.setenv("DAFS_HIP_DD_SPLIT", "0")
+    ref = pipeline.run(names, seqs, bp=bp, t_max=12, level_sync=True, skip_uncoupled_folds=False)
+    assert ref.output == want and ref.dd_log == got.dd_log
