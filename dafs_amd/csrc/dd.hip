@@ -17,7 +17,9 @@
 // candidate split points and traceback codes in LDS (the codes in HBM from ~415 columns on; 48 lanes of up
 // to 16 columns from 513 to 768), followed by their tracebacks (the folding one by the whole wavefront, run
 // by run); the multiplier update is parallel over the sparse consensus structure.
-// Forms that do not fit LDS fall back to the same DPs over HBM/L2 tables (nuss_wave, nw_wave).  Float sums
+// A folding DP that has no register form (beyond 768 columns) or whose register form overflows its candidate
+// slots falls back to the span-ordered form of the standalone decoder on all threads of its workgroup
+// (nuss_pair_dp); an alignment DP that does not fit falls back to the wave form over HBM/L2 tables (nw_wave).  Float sums
 // that the reference forms sequentially (the dual value s, which steers the step size) are formed in the
 // same order: positive terms are compacted in consensus-pair order and added by one lane.
 // The standalone decoders (k_nussinov_single, k_nw_single: the plugin entry points and the final consensus
@@ -251,95 +253,8 @@ __device__ __forceinline__ void st_l2g(DD_GLB float* p, float v) { __hip_atomic_
 __device__ __forceinline__ void st_l2(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ size_t tri_index(uint32_t L, uint32_t i, uint32_t j) { return (size_t)i * L - (size_t)i * (i - 1) / 2 + (j - i); }  // j >= i
 
-// SparseNussinov::decode DP (nussinov.cpp:217-263) by one wavefront.  Rows run from L-1 down to 0
-// (row i at step (L-1-i)+lane), which visits the cells of a column in the same order as the
-// reference's span loop, so the per-column candidate lists are built in the same order.
-// trb: one byte per upper-triangle cell (0..3, 4 = bifurcation with k in trk); dp/ck/cv in HBM
-// (dp read back for the bifurcation terms through L2); cc, P in LDS.
-#define DD_WMAX 16  // columns per lane whose next-step inputs are prefetched through registers; wider lanes (alignments
+#define DD_WMAX 16  // columns per lane whose next-step inputs are prefetched through registers by nw_wave; wider lanes (alignments
                    // beyond 1024 columns, up to DD_LMAX) fetch the rest at the end of the step
-
-// S: pair scores w*(p-th)-q (or p-th), precomputed by the whole workgroup (dd_fill_scores).  Row i of S
-// is fetched one step ahead into registers (16 independent loads) and parked in LDS (Sb) for the next step,
-// so no global-memory latency sits on the per-cell dependency chain.
-__device__ float nuss_wave(uint32_t L, const float* __restrict__ S_, const nuss_ws& ws, uint8_t* trb_, uint32_t* trk_, float* P_, float* Sb_,
-                           uint32_t* cc_, int lane) {
-  DD_GLB const float* S = (DD_GLB const float*)S_;
-  DD_GLB uint8_t* trb = (DD_GLB uint8_t*)trb_;
-  DD_GLB uint32_t* trk = (DD_GLB uint32_t*)trk_;
-  DD_GLB float* dpg = (DD_GLB float*)ws.dp;
-  DD_GLB uint32_t* ckg = (DD_GLB uint32_t*)ws.ck;
-  DD_GLB float* cvg = (DD_GLB float*)ws.cv;
-  DD_LDS float* P = (DD_LDS float*)P_;
-  DD_LDS float* Sb = (DD_LDS float*)Sb_;
-  DD_LDS uint32_t* cc = (DD_LDS uint32_t*)cc_;
-  const uint32_t W = dd_fold_cols(L);
-  for (uint32_t c = 0; c < W; ++c) {
-    P[c * 64 + lane] = 0.0f;
-    Sb[c * 64 + lane] = 0.0f;
-    const uint32_t j = lane * W + c;
-    if (j < L) cc[j] = 0;
-  }
-  float last = 0.0f, leftprev = 0.0f, score = 0.0f;
-  const int nsteps = (int)L + (int)((L + W - 1) / W) - 1;  // the last lane that owns a column finishes row 0 here
-  for (uint32_t c = 0; c < W; ++c) Sb[c * 64 + lane] = S[(size_t)c * 64 + lane];  // step 0
-  for (int s = 0; s < nsteps; ++s) {
-    const int i = (int)L - 1 - (s - lane);
-    const bool rowv = i >= 0 && i < (int)L;
-    // prefetch the scores of the next step (coalesced: S is stored in sweep order)
-    float nxt[DD_WMAX];
-    const bool nv = s + 1 < nsteps;
-#pragma unroll
-    for (int c = 0; c < DD_WMAX; ++c) nxt[c] = (nv && (uint32_t)c < W) ? S[((size_t)(s + 1) * W + c) * 64 + lane] : 0.0f;
-    float recv = __shfl_up(last, 1);
-    if (lane == 0) recv = 0.0f;
-    float diag = leftprev;  // dp[i+1][j-1]
-    float left = recv;      // dp[i][j-1]
-    float v = 0.0f;
-    for (uint32_t c = 0; c < W; ++c) {
-      const uint32_t j = lane * W + c;
-      const float below = P[c * 64 + lane];  // dp[i+1][j]
-      v = 0.0f;
-      if (rowv && j < L && (int)j > i) {
-        const uint32_t ui = (uint32_t)i;
-        uint32_t t = 0;
-        if (ui + 1 < j) { v = below; t = 1; }
-        if (ui < j - 1 && v < left) { v = left; t = 2; }
-        const uint32_t n = cc[j];
-        if (ui + 1 < j - 1) {
-          const float sc = Sb[c * 64 + lane];  // nussinov.cpp:236 / :329
-          if (sc > 0.0f) {
-            const float cand = diag + sc;
-            ckg[(size_t)j * L + n] = ui;
-            cvg[(size_t)j * L + n] = cand;
-            cc[j] = n + 1;
-            if (v < cand) { v = cand; t = 3; }
-          }
-        }
-        for (uint32_t x = 0; x < n; ++x) {
-          const uint32_t k = ckg[(size_t)j * L + x];
-          const float dik = (k - 1 == ui) ? 0.0f : ld_l2g(&dpg[(size_t)ui * L + k - 1]);  // dp[i][i] = 0 is never stored
-          const float cand = dik + cvg[(size_t)j * L + x];
-          if (v < cand) { v = cand; t = k - ui + 3; }
-        }
-        st_l2g(&dpg[(size_t)ui * L + j], v);
-        trb[tri_index(L, ui, j)] = (uint8_t)(t < 4 ? t : 4);
-        if (t >= 4) trk[(size_t)ui * L + j] = t;
-        if (ui == 0 && j == L - 1) score = v;
-      }
-      diag = below;
-      P[c * 64 + lane] = v;
-      left = v;
-    }
-    leftprev = recv;
-    last = v;
-#pragma unroll
-    for (int c = 0; c < DD_WMAX; ++c)
-      if ((uint32_t)c < W) Sb[c * 64 + lane] = nxt[c];
-    for (uint32_t c = DD_WMAX; c < W; ++c) Sb[c * 64 + lane] = nv ? S[((size_t)(s + 1) * W + c) * 64 + lane] : 0.0f;
-  }
-  return __shfl(score, (int)((L - 1) / W));
-}
 
 // Register-resident forms (W columns per lane, a template constant: up to DD_WREG for the alignment DP and for
 // the folding DP with its codes in LDS, up to DD_WFOLD for the folding DP with its codes in HBM): the previous
@@ -359,7 +274,7 @@ __device__ __forceinline__ float wave_shr1(float v) {
 // the prefetch of the next step is waited for at once.  Hence: traceback codes in LDS (a bifurcation
 // is recorded as 4 + the index of its candidate, whose split row is read back from lck), and a column that
 // collects more than DD_CAP candidates raises `ovf`; the caller then repeats the DP with
-// nuss_wave, which works in global memory.
+// nuss_pair_dp, the span-ordered form in global memory.
 // TRG: the traceback codes go to HBM instead (one byte per cell of the upper triangle, trbg_) for alignments whose
 // nibble table no longer fits beside the rows in flight.  That puts stores into the loop, so every wait for the
 // prefetched scores also waits for them; with the seven or more cells per lane of such alignments a step is
@@ -518,7 +433,7 @@ __device__ __noinline__ float nuss_wave_fast_t(uint32_t W, uint32_t L, const flo
       default: break;
     }
   }
-  *ovf = true;  // no register form for this width: the caller falls back to nuss_wave
+  *ovf = true;  // no register form for this width: the caller falls back to the span-ordered form
   return 0.0f;
 }
 // trb (LDS nibbles) when the fold was granted room for them, else the byte table trbg in HBM
@@ -526,7 +441,6 @@ __device__ __forceinline__ float nuss_wave_fast(uint32_t W, uint32_t L, const fl
   return trb ? nuss_wave_fast_t<false>(W, L, S, trb, trbg, ring, lck, lane, ovf) : nuss_wave_fast_t<true>(W, L, S, trb, trbg, ring, lck, lane, ovf);
 }
 
-// traceback of nuss_wave_reg's codes (see nuss_traceback_b for the walk)
 // Traceback of nuss_wave_reg's codes by the whole wavefront.  The walk itself is sequential, but it consists
 // of runs: stretches of code 1 (i+1), of code 2 (j-1) and stacks of code 3 (i+1, j-1).  The lanes read the
 // next 64 cells along the current direction at once and a ballot finds where the run ends, so a run costs
@@ -688,33 +602,6 @@ __device__ void dd_fill_nw(uint32_t L1, uint32_t L2, const float* __restrict__ p
   }
 }
 
-__device__ void nuss_traceback_b(uint32_t L, const uint8_t* trb, const uint32_t* trk, uint32_t* ss, uint32_t* stack) {
-  // The segment being followed stays in registers; only the left half of a bifurcation is parked on
-  // the stack (LDS, one packed word per segment, at most L/2 deep).  The pairs written do not depend
-  // on the order the segments are visited in.
-  uint32_t sp = 0;
-  int i = 0, j = (int)L - 1;
-  uint32_t guard = 4 * L + 8;
-  while (guard--) {
-    uint32_t t = 0;
-    if (j > i) t = trb[tri_index(L, (uint32_t)i, (uint32_t)j)];  // tr of the diagonal is 0
-    if (t == 0) {
-      if (!sp) break;
-      const uint32_t e = stack[--sp];
-      i = (int)(e >> 16); j = (int)(e & 0xFFFFu);
-      continue;
-    }
-    if (t == 1) ++i;
-    else if (t == 2) --j;
-    else if (t == 3) { ss[i] = j; ++i; --j; }
-    else {
-      const int k = i + (int)trk[(size_t)i * L + j] - 3;
-      ss[k] = j;
-      if (k - 1 > i) stack[sp++] = ((uint32_t)i << 16) | (uint32_t)(k - 1);
-      i = k + 1; --j;
-    }
-  }
-}
 
 // SparseNeedlemanWunsch::decode DP (needleman_wunsch.cpp:276-296) by one wavefront; row i at step
 // i-1+lane.  Cells outside the envelope hold lowest(), row 0 / column 0 hold 0.  tr must have been
@@ -1256,6 +1143,8 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
   __shared__ int s_stop, s_bad;
   __shared__ float s_eta;
   __shared__ float s_score[3];
+  __shared__ uint32_t s_slowxy[2];       // this iteration's x / y folding is still to be done by the span-ordered form
+  bool gave_up_x = false, gave_up_y = false;
   float c = 0.0f, eta = prm.eta0, s_prev = 0.0f;  // meaningful in thread 0
   uint32_t t = 0, violated = 0;
   const bool resume = nd.info[6] != 0;  // a node paused by an earlier launch (prm.slice): pick up its loop state
@@ -1303,10 +1192,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     if (fastx) Px = ringx;
     if (fasty) Py = ringy;
   }
-  float* Sbx = Px + Wx * 64;
-  float* Sby = Py + Wy * 64;
-  uint32_t* ccx = (uint32_t*)(Sbx + Wx * 64);
-  uint32_t* ccy = (uint32_t*)(Sby + Wy * 64);
+
   const bool shared_xy = (nd.lds_flags & 8) != 0;
   __shared__ uint32_t s_x_done;  // iteration whose x folding (DP + traceback) has released the shared region
   if (tid == 0) s_x_done = 0xFFFFFFFFu;
@@ -1339,6 +1225,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
       for (uint32_t i = tid; i < L1; i += nt) nd.x[i] = DD_NONE;
       for (uint32_t k = tid; k < L2; k += nt) nd.y[k] = DD_NONE;
     }
+    if (tid == 0) { s_slowxy[0] = 0; s_slowxy[1] = 0; }
     // packed traceback tables are filled by OR
     if (trzp) for (uint32_t e = tid; e < nzw; e += nt) trzp[e] = 0;
     if (trxp) for (uint32_t e = tid; e < nxw; e += nt) trxp[e] = 0;
@@ -1352,13 +1239,11 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     } else if (wave == 0) {
       bool slow = true;
       float sc = 0.0f;
-      if (ringx && Wx <= DD_WFOLD) sc = nuss_wave_fast(Wx, L1, nd.s_x, trxp, nd.trb_x, ringx, lckx, lane, &slow);
+      if (ringx && !gave_up_x && Wx <= DD_WFOLD) sc = nuss_wave_fast(Wx, L1, nd.s_x, trxp, nd.trb_x, ringx, lckx, lane, &slow);
       if (slow && lane == 0 && prm.stamps) nd.info[4] += 1;  // iterations that took the slower form
-      if (slow) sc = nuss_wave(L1, nd.s_x, nd.wx, nd.trb_x, nd.trk_x, Px, Sbx, ccx, lane);
+      if (lane == 0) { s_slowxy[0] = slow ? 1u : 0u; s_score[0] = sc; }  // slow: the span-ordered form below, by everybody
       DD_TICK(0);
-      if (lane == 0) s_score[0] = sc;
       if (!slow) nuss_traceback_fast(L1, trxp, nd.trb_x, lckx, nd.x, (uint32_t*)Px, lane);
-      else if (lane == 0) nuss_traceback_b(L1, nd.trb_x, nd.trk_x, nd.x, (uint32_t*)Px);
       DD_TICK(1);
       if (shared_xy) {  // hand the region to the y folding
         wave_lds_fence();
@@ -1372,12 +1257,10 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
         if (tryp) for (uint32_t e = (uint32_t)lane; e < nyw; e += 64) tryp[e] = 0;
         wave_lds_fence();
       }
-      if (ringy && Wy <= DD_WFOLD) sc = nuss_wave_fast(Wy, L2, nd.s_y, tryp, nd.trb_y, ringy, lcky, lane, &slow);
+      if (ringy && !gave_up_y && Wy <= DD_WFOLD) sc = nuss_wave_fast(Wy, L2, nd.s_y, tryp, nd.trb_y, ringy, lcky, lane, &slow);
       if (slow && lane == 0 && prm.stamps) nd.info[5] += 1;
-      if (slow) sc = nuss_wave(L2, nd.s_y, nd.wy, nd.trb_y, nd.trk_y, Py, Sby, ccy, lane);
-      if (lane == 0) s_score[1] = sc;
+      if (lane == 0) { s_slowxy[1] = slow ? 1u : 0u; s_score[1] = sc; }
       if (!slow) nuss_traceback_fast(L2, tryp, nd.trb_y, lcky, nd.y, (uint32_t*)Py, lane);
-      else if (lane == 0) nuss_traceback_b(L2, nd.trb_y, nd.trk_y, nd.y, (uint32_t*)Py);
     }
     if (wave == 2) {
       float sc;
@@ -1407,6 +1290,20 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
       }
     }
     __syncthreads();
+    {
+      // Foldings whose register form gave up (more than DD_CAP candidates in a column) or does not exist for this
+      // width: the span-ordered form of the standalone decoder, both at once, on all threads; and no further
+      // register attempts in this launch.
+      const bool slx = s_slowxy[0] != 0, sly = s_slowxy[1] != 0;
+      gave_up_x = gave_up_x || slx;
+      gave_up_y = gave_up_y || sly;
+      if (slx || sly) {
+        nuss_pair_dp(slx ? L1 : 0u, nd.p_x, nd.q_x, w_x, nd.wx, sly ? L2 : 0u, nd.p_y, nd.q_y, w_y, nd.wy, prm.th_s);
+        if (tid == 0 && slx) { nuss_traceback(L1, nd.wx, nd.x, nd.wx.ck); s_score[0] = nd.wx.dp[L1 - 1]; }
+        if (tid == 64 && sly) { nuss_traceback(L2, nd.wy, nd.y, nd.wy.ck); s_score[1] = nd.wy.dp[L2 - 1]; }
+        __syncthreads();
+      }
+    }
     DD_TICK(2);
 
     // consensus constraints (:1103-1117): counts by atomics, positive s_w compacted in order
