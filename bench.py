@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--n-seq", type=int, default=0, help="override the number of sequences")
     ap.add_argument("--length", type=int, default=BASE_L)
     ap.add_argument("--th", type=float, default=0.01)
+    ap.add_argument("--model", choices=("probcons", "contralign"), default="probcons", help="alignment model of the timed kernel")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end wall-clock leg")
     args = ap.parse_args()
@@ -124,7 +125,9 @@ def main():
     rp_off = np.concatenate([[0], np.cumsum(rp_sizes)])[:-1].astype(np.uint64)
     rp_total = int(rp_sizes.sum())
     plan = capi.PairhmmPlan()
-    capi.check(capi.pairhmm_plan(np_local, int(lens[px].max()), int(lens[py].max()), plan))
+    contra = args.model == "contralign"
+    plan_fn, launch_fn = (capi.pairhmm5_plan, capi.pairhmm5_launch) if contra else (capi.pairhmm_plan, capi.pairhmm3_launch)
+    capi.check(plan_fn(np_local, int(lens[px].max()), int(lens[py].max()), plan))
     pool_cap = int(2 * 24 * np.minimum(lens[px], lens[py]).sum())
 
     d_codes = torch.from_numpy(codes).to(dev)
@@ -144,14 +147,14 @@ def main():
              "pair_off": torch.empty(np_local, dtype=torch.int64, device=dev),
              "pair_nnz": torch.empty(np_local, dtype=torch.int32, device=dev),
              "sim": torch.empty(np_local, dtype=torch.float32, device=dev)}
-        a = capi.Pairhmm3Args()
+        a = capi.Pairhmm5Args() if contra else capi.Pairhmm3Args()
         a.codes = d_codes.data_ptr(); a.tasks = d_tasks.data_ptr(); a.ntasks = np_local; a.th = args.th
         a.scratch = d_scratch.data_ptr()
         a.pool_top = o["counters"].data_ptr(); a.queue = o["counters"].data_ptr() + 8; a.status = o["counters"].data_ptr() + 16
         a.rp_off = d_rp_off.data_ptr(); a.rowptr_pool = o["rowptr"].data_ptr()
         a.ent_col = o["col"].data_ptr(); a.ent_val = o["val"].data_ptr(); a.pool_cap = pool_cap
         a.pair_off = o["pair_off"].data_ptr(); a.pair_nnz = o["pair_nnz"].data_ptr(); a.sim = o["sim"].data_ptr()
-        capi.pairhmm3_default_model(C.byref(a.model))
+        (capi.pairhmm5_default_model if contra else capi.pairhmm3_default_model)(C.byref(a.model))
         o["args"] = a
         o["gathered"] = None  # event: the exchange that read this set has finished
         sets.append(o)
@@ -178,7 +181,7 @@ def main():
         o["counters"].zero_()
         if k is not None:
             ev0[k].record(stream)
-        capi.check(capi.pairhmm3_launch(C.byref(o["args"]), C.byref(plan), C.c_void_p(stream.cuda_stream)))
+        capi.check(launch_fn(C.byref(o["args"]), C.byref(plan), C.c_void_p(stream.cuda_stream)))
         if k is not None:
             ev1[k].record(stream)
         if ex is not None:
@@ -226,14 +229,16 @@ def main():
         dt = float(tt.item())
 
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in zip(ev0, ev1)]))
-    # algorithmic bytes: 28*(L1+1)*(L2+1) per pair = fwd 12C + bwd 12C + posterior 4C
-    alg_bytes = float((28 * (lens[px] + 1) * (lens[py] + 1)).sum())
+    # algorithmic bytes: ProbCons 28*(L1+1)*(L2+1) per pair = fwd 12C + bwd 12C + posterior 4C;
+    # CONTRAlign 44*C = (5 + 5) tables * 4C + posterior 4C
+    alg_bytes = float(((44 if contra else 28) * (lens[px] + 1) * (lens[py] + 1)).sum())
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
     # HBM traffic of the dominant kernel: from the committed rocprofv3 PMC passes (profiles/*_pmc.json,
     # collected and corrected as MI355X_MICROARCH.md prescribes); only quoted when it is the same kernel.
     traffic = None
-    kernel_name = "k_pairhmm3<G=%d,W=%d" % (plan.group, plan.width)
+    kname = "k_pairhmm5" if contra else "k_pairhmm3"
+    kernel_name = "%s<G=%d,W=%d" % (kname, plan.group, plan.width)
     try:
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
@@ -268,7 +273,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "seq-pairs/sec (all-pairs ProbCons pair-HMM posteriors + sparse rows + sim)",
+            "metric": "seq-pairs/sec (all-pairs %s pair-HMM posteriors + sparse rows + sim)" % ("CONTRAlign" if contra else "ProbCons"),
             "value": total_pairs * args.steps / dt,
             "unit": "seq-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -278,8 +283,8 @@ def main():
             "config": {"workload": "N=%d L~%d synthetic random RNA (seed 12345), %d pairs%s" %
                                    (n_seq, args.length, total_pairs,
                                     "" if world == 1 else ", dealt by cost to %d ranks + 1 all-gather" % world),
-                       "align_model": "ProbCons", "th": args.th,
-                       "kernel": "k_pairhmm3<G=%d,W=%d> x %d waves" % (plan.group, plan.width, plan.nwaves)},
+                       "align_model": "CONTRAlign" if contra else "ProbCons", "th": args.th,
+                       "kernel": "%s<G=%d,W=%d> x %d waves" % (kname, plan.group, plan.width, plan.nwaves)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},

@@ -18,6 +18,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall",
          "-Wno-unused-function", "-Wno-missing-braces", "-fno-fast-math"]
 FLAGS += os.environ.get("DAFS_HIP_EXTRA_FLAGS", "").split()  # tuning experiments only
+# Per-file flags.  The pair kernels run four or more wavefronts per SIMD, where a packed-f32 instruction costs as much
+# as two plain ones and plain f32 adds/multiplies issue 2.5x faster than anything else (profiles/r02_a_valu_rate.txt):
+# the SLP vectoriser's automatic v_pk_* pairs (plus the moves that line their operands up) are a loss there.
+FILE_FLAGS = {"pairhmm3.hip": ["-fno-slp-vectorize"], "pairhmm5.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -38,7 +42,7 @@ def _compile(name, force):
     obj = os.path.join(OBJ, name + ".o")
     if not force and not _stale(src, obj):
         return obj
-    cmd = [HIPCC] + FLAGS + (["-x", "hip"] if name.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(name, []) + (["-x", "hip"] if name.endswith(".cpp") else []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s" % (name, r.stderr))

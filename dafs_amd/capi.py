@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdafs_hip.so")
+LIB_PATH = os.environ.get("DAFS_HIP_LIB") or os.path.join(_HERE, "libdafs_hip.so")  # DAFS_HIP_LIB: tuning builds
 
 NONE = 0xFFFFFFFF
 ALIGN_PROBCONS, ALIGN_CONTRALIGN = 0, 1
@@ -49,6 +49,15 @@ class Pairhmm3Args(C.Structure):
                 ("ent_col", C.c_void_p), ("ent_val", C.c_void_p), ("pool_top", C.c_void_p), ("pool_cap", C.c_uint64),
                 ("pair_off", C.c_void_p), ("pair_nnz", C.c_void_p), ("sim", C.c_void_p), ("status", C.c_void_p),
                 ("model", Pairhmm3Model)]
+
+
+class Pairhmm5Model(C.Structure):
+    _fields_ = [("match", (C.c_float * 5) * 5), ("insert", C.c_float * 5), ("single", C.c_float * 5),
+                ("pair", (C.c_float * 5) * 5)]
+
+
+class Pairhmm5Args(C.Structure):
+    _fields_ = Pairhmm3Args._fields_[:-1] + [("model", Pairhmm5Model)]
 
 
 def _sig(name, restype, argtypes):
@@ -120,6 +129,9 @@ _consensus_structure = _sig("dafs_hip_consensus_structure", C.c_int,
 pairhmm_plan = _sig("dafs_hipk_pairhmm_plan", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PairhmmPlan)])
 pairhmm3_launch = _sig("dafs_hipk_pairhmm3_launch", C.c_int, [C.POINTER(Pairhmm3Args), C.POINTER(PairhmmPlan), C.c_void_p])
 pairhmm3_default_model = _sig("dafs_hip_pairhmm3_default_model", None, [C.POINTER(Pairhmm3Model)])
+pairhmm5_plan = _sig("dafs_hipk_pairhmm5_plan", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PairhmmPlan)])
+pairhmm5_launch = _sig("dafs_hipk_pairhmm5_launch", C.c_int, [C.POINTER(Pairhmm5Args), C.POINTER(PairhmmPlan), C.c_void_p])
+pairhmm5_default_model = _sig("dafs_hip_pairhmm5_default_model", None, [C.POINTER(Pairhmm5Model)])
 residue_code = _sig("dafs_hip_residue_code", C.c_uint8, [C.c_char])
 
 

@@ -35,8 +35,12 @@
 
 namespace dafs {
 
-template <int G, int W, bool LUT>
-__global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t slab_steps, uint32_t rp_cap) {
+// OCC = wavefronts per SIMD the register allocation must leave room for (the planner reads the result back
+// from the code object).  The sweeps wait on an LDS lookup in every log-sum-exp, so resident wavefronts are
+// what keeps the vector pipe busy: 2 per SIMD reach a third of its issue rate.
+template <int G, int W, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t slab_steps, uint32_t rp_cap) {
+  constexpr bool LUT = true;
   constexpr int NG = 64 / G;  // pairs per wavefront
   extern __shared__ uint32_t s_dyn[];  // per (wave, group): rp_cap row pointers
   __shared__ float s_match[56];
@@ -53,7 +57,9 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
   const int t = lane % G;
   const int g = lane / G;
   const int wave_in_wg = threadIdx.x >> 6;
-  const uint32_t wave = blockIdx.x * 4 + wave_in_wg;
+  // wave-uniform slab base (readfirstlane: the compiler cannot see that threadIdx.x >> 6 is uniform): slab accesses
+  // then take a scalar base + the lane's 4*lane + an immediate, with no vector address arithmetic
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave_in_wg);
   float* __restrict__ slab = a.scratch + (size_t)wave * slab_steps * W * 64;
   uint32_t* __restrict__ s_rowptr = s_dyn + (size_t)(wave_in_wg * NG + g) * rp_cap;
 
@@ -82,15 +88,23 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
     int maxL1 = L1;
 #pragma unroll
     for (int o = G; o < 64; o <<= 1) maxL1 = max(maxL1, __shfl_xor(maxL1, o));
-    const int nsteps = maxL1 + G;
+    const int nsteps = __builtin_amdgcn_readfirstlane(maxL1) + G;
+    // columns per lane of this wave: W, or W-1 when its pairs fit (pair_sweeps.h)
+    const int wr = pair_width<G, W>(L2);
+    const bool full = wr == W;
+    const int j0 = t * wr;
 
     // residue classes of this lane's columns: cc[c] = class of column j=t*W+c (s2[j-1]); 6 = other
     int cc[W + 1];
 #pragma unroll
     for (int c = 0; c <= W; ++c) {
-      const int j = t * W + c;
+      const int j = j0 + c;
       cc[c] = (j >= 1 && j <= L2) ? (int)s2[j - 1] : 6;
     }
+    const int tlast = (L2 >= 0 ? L2 : 0) / wr;  // lane (within group) that owns column L2
+    float ins2[W + 1];  // single-emission score of this lane's columns (a register instead of an LDS lookup per cell)
+#pragma unroll
+    for (int c = 0; c <= W; ++c) ins2[c] = s_ins[cc[c]];
     const int c1first = act ? (int)s1[0] : 6;
     const int c2first = act ? (int)s2[0] : 6;
     // the three initial cells (ProbabilisticModel.h:123-131)
@@ -112,6 +126,7 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
       for (int s = 0; s < nsteps; ++s) {
         const int i = s - t;
         const bool rowv = (i >= 0) && (i <= L1);
+        float* __restrict__ slab_s = slab + (size_t)s * (W * 64);
         const int c1 = (rowv && i >= 1) ? (int)s1[i - 1] : 6;
         const float rM = shift_up1<G>(lastM, LZ, t), rX = shift_up1<G>(lastX, LZ, t), rY = shift_up1<G>(lastY, LZ, t);
         float dM = dgM, dX = dgX, dY = dgY;  // (i-1, j-1)
@@ -119,36 +134,43 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
         const float insc1 = s_ins[c1];
 #pragma unroll
         for (int c = 0; c < W; ++c) {
-          const int j = t * W + c;
-          const float mt = s_match[c1 * 8 + cc[c]];
-          // ProbabilisticModel.h:152-155 (M), :159-161 (X), :165-167 (Y): four LOG_ADDs, issued as two
-          // packed pairs -- M's first with X's, then M's second with Y's
-          const pc_f2 r1 = pc_log_add2<LUT>(&s_tab, pc_f2{dM + tMM, pM[c] + tMX}, pc_f2{dX + tXM, pX[c] + tXX});
-          const pc_f2 r2 = pc_log_add2<LUT>(&s_tab, pc_f2{r1.x, lM + tMY}, pc_f2{dY + tYM, lY + tYY});
-          float m = r2.x + mt;
-          float x = insc1 + r1.y;
-          float y = s_ins[cc[c]] + r2.y;
-          if (c <= 1) {  // j <= 1 needs c <= 1: initial cells, :123-131 (cells with i<=1 && j<=1 are skipped by :150)
-            if (i <= 1 && j <= 1) {
-              m = (i == 1 && j == 1) ? fM11 : LZ;
-              x = (i == 1 && j == 0) ? fX10 : LZ;
-              y = (i == 0 && j == 1) ? fY01 : LZ;
+          if (c < W - 1 || full) {
+            const int j = j0 + c;
+            const float mt = s_match[c1 * 8 + cc[c]];
+            // ProbabilisticModel.h:152-155 (M), :159-161 (X), :165-167 (Y): four LOG_ADDs
+            const float m1 = pc_log_add_q(&s_tab, dM + tMM, dX + tXM);
+            const float xx = pc_log_add_q(&s_tab, pM[c] + tMX, pX[c] + tXX);
+            const float m2 = pc_log_add_q(&s_tab, m1, dY + tYM);
+            const float yy = pc_log_add_q(&s_tab, lM + tMY, lY + tYY);
+            float m = m2 + mt;
+            float x = insc1 + xx;
+            float y = ins2[c] + yy;
+            if (c <= 1) {  // j <= 1 needs c <= 1: initial cells, :123-131 (cells with i<=1 && j<=1 are skipped by :150)
+              if (i <= 1 && j <= 1) {
+                m = (i == 1 && j == 1) ? fM11 : LZ;
+                x = (i == 1 && j == 0) ? fX10 : LZ;
+                y = (i == 0 && j == 1) ? fY01 : LZ;
+              }
             }
+            dM = pM[c]; dX = pX[c]; dY = pY[c];
+            pM[c] = m; pX[c] = x; pY[c] = y;
+            lM = m; lY = y;
+            slab_s[c * 64 + lane] = m;  // slot (s,c,lane) is private to this lane: no guard needed
           }
-          dM = pM[c]; dX = pX[c]; dY = pY[c];
-          pM[c] = m; pX[c] = x; pY[c] = y;
-          lM = m; lY = y;
-          slab[(size_t)(s * W + c) * 64 + lane] = m;  // slot (s,c,lane) is private to this lane: no guard needed
-          if (i == L1 && j == L2) { endM = m; endX = x; endY = y; }
         }
         dgM = rM; dgX = rX; dgY = rY;
-        lastM = pM[W - 1]; lastX = pX[W - 1]; lastY = pY[W - 1];
+        lastM = lM; lastX = full ? pX[W - 1] : pX[W > 1 ? W - 2 : 0]; lastY = lY;
+        if (i == L1 && t == tlast) {  // F_k(L1, L2): one lane of the group, once (a rare branch instead of three selects per cell)
+          const int cl = L2 - j0;
+#pragma unroll
+          for (int c = 0; c < W; ++c)
+            if (c == cl) { endM = pM[c]; endX = pX[c]; endY = pY[c]; }
+        }
       }
     }
 #if defined(PAIR_EXP_STOP) && PAIR_EXP_STOP == 1  // tuning experiment: time of the forward sweep alone
     if (endM != 12345.0f) continue;
 #endif
-    const int tlast = (L2 >= 0 ? L2 : 0) / W;  // lane (within group) that owns column L2
     float totF = LZ;  // ComputeTotalProbability, :341-347 (B_k(L1,L2) = init_k)
     totF = pc_log_add_t<LUT>(&s_tab, totF, endM + i0);
     totF = pc_log_add_t<LUT>(&s_tab, totF, endX + i1);
@@ -164,10 +186,13 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
       float firstM = LZ, firstY = LZ;  // this lane's first column, row of the previous step
       float dgM = LZ;                  // right neighbour's first column, one row later
       for (int s = 0; s < nsteps; ++s) {
-        // mirrored skew: lane G-1 starts with the last row
-        const int i = L1 - s + (G - 1 - t);
+        // mirrored skew: lane G-1 starts with the last row of the longest pair of the wave (rows beyond a shorter
+        // pair's L1 stay LOG_ZERO like every other cell outside the grid), so that the forward step that
+        // stored row i for this lane, sf = i + t, is the same for the whole wave
+        const int sf = nsteps - 1 - s;
+        const int i = sf - t;
         const bool rowv = (i >= 0) && (i <= L1);
-        const int sf = i + t;  // forward step that stored row i for this lane (wave-uniform per group)
+        float* __restrict__ slab_s = slab + (size_t)sf * (W * 64);
         const int c1 = (rowv && i < L1) ? (int)s1[i] : 6;
         const float rM = shift_down1<G>(firstM, LZ, t), rY = shift_down1<G>(firstY, LZ, t);
         float dM = dgM;  // B_M(i+1, j+1)
@@ -176,12 +201,13 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
         float fwd[W];
 #pragma unroll
         for (int c = 0; c < W; ++c) {
-          const int j = t * W + c;
-          fwd[c] = (rowv && j <= L2) ? slab[(size_t)(sf * W + c) * 64 + lane] : 0.0f;
+          const int j = j0 + c;
+          if (c < W - 1 || full) fwd[c] = (rowv && j <= L2) ? slab_s[c * 64 + lane] : 0.0f;
         }
 #pragma unroll
         for (int c = W - 1; c >= 0; --c) {
-          const int j = t * W + c;
+          if (!(c < W - 1 || full)) continue;
+          const int j = j0 + c;
           const int c2 = cc[c + 1];  // class of s2[j] (iter2[j+1]); 'other' beyond the end
           // :233-237.  The cells start at LOG_ZERO (:213-214 sets the corner to the initial distribution), and
           // LOG_ZERO (+) v == v for every v >= LOG_ZERO (the d >= 7.5 exit; v == LOG_ZERO gives LOG_ZERO), so
@@ -190,16 +216,17 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
           const float pxy = dM + s_match[c1 * 8 + c2];
           float bm = pxy + tMM, bx = pxy + tXM, by = pxy + tYM;
           if (i == L1 && j == L2) { bm = i0; bx = i1; by = i2; }
-          // :238-243 (M and X take the X-step term) and :244-249 (M and Y take the Y-step term), each a packed pair
+          // :238-243 (M and X take the X-step term) and :244-249 (M and Y take the Y-step term)
           const float tx = pX[c] + insc1;
-          const pc_f2 q1 = pc_log_add2<LUT>(&s_tab, pc_f2{bm, bx}, pc_f2{tx + tMX, tx + tXX});
-          const float ty = rgY + s_ins[c2];
-          const pc_f2 q2 = pc_log_add2<LUT>(&s_tab, pc_f2{q1.x, by}, pc_f2{ty + tMY, ty + tYY});
-          bm = q2.x; bx = q1.y; by = q2.y;
+          bm = pc_log_add_q(&s_tab, bm, tx + tMX);
+          bx = pc_log_add_q(&s_tab, bx, tx + tXX);
+          const float ty = rgY + ins2[c + 1];
+          bm = pc_log_add_q(&s_tab, bm, ty + tMY);
+          by = pc_log_add_q(&s_tab, by, ty + tYY);
           dM = pM[c];
           pM[c] = bm; pX[c] = bx;
           rgY = by;
-          if (rowv && j <= L2) slab[(size_t)(sf * W + c) * 64 + lane] = fwd[c] + bm;  // forward[ij] + backward[ij], :395
+          if (rowv && j <= L2) slab_s[c * 64 + lane] = fwd[c] + bm;  // forward[ij] + backward[ij], :395
           if (c <= 1) {  // columns 0 and 1 only exist for c <= 1
             if (i == 1 && j == 1) capM = bm;
             if (i == 1 && j == 0) capX = bx;
@@ -215,9 +242,9 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
     if (capM != 12345.0f) continue;
 #endif
     // ComputeTotalProbability, :349-364
-    capM = __shfl(capM, g * G + (1 / W));
+    capM = __shfl(capM, g * G + (1 / wr));
     capX = __shfl(capX, g * G);
-    capY = __shfl(capY, g * G + (1 / W));
+    capY = __shfl(capY, g * G + (1 / wr));
     float totB = fM11 + capM;
     totB = pc_log_add_t<LUT>(&s_tab, totB, fX10 + capX);
     totB = pc_log_add_t<LUT>(&s_tab, totB, fY01 + capY);
@@ -225,7 +252,7 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
 
     // sweeps 3 + 4 (pair_sweeps.h): ComputePosteriorMatrix :395 = EXP(min(LOG_ONE, F+B-total)), then sparse outputs
     const pc_tables* tab = &s_tab;
-    pair_finish<G, W>(a, slab, s_rowptr, lane, t, g, L1, L2, nsteps, tlast, act, task, th, [total, tab](float sv) {
+    pair_finish<G, W>(a, slab, s_rowptr, lane, t, g, L1, L2, nsteps, wr, act, task, th, [total, tab](float sv) {
       const float e = sv - total;
       return pc_exp_t(tab, e < 0.0f ? e : 0.0f);
     });
@@ -235,23 +262,15 @@ __global__ __launch_bounds__(256) void k_pairhmm3(dafs_pairhmm3_args a, uint32_t
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-typedef void (*pairhmm3_fn)(dafs_pairhmm3_args, uint32_t, uint32_t);
-struct variant { int G, W; pairhmm3_fn fn; pairhmm3_fn fn_alt; };
-#define V(G, W) {G, W, k_pairhmm3<G, W, true>, nullptr}
-#define V2(G, W) {G, W, k_pairhmm3<G, W, true>, k_pairhmm3<G, W, false>}
-static const variant k_variants[] = {
-    V(16, 2), V(16, 3), V(16, 4), V(16, 5), V(16, 6), V(16, 8), V(16, 10), V2(16, 11), V(16, 12), V(16, 14), V(16, 16),
-    V(32, 2), V(32, 3), V(32, 4), V(32, 5), V2(32, 6), V(32, 8), V(32, 10), V(32, 12), V(32, 14), V(32, 16),
-    V(64, 1), V(64, 2), V2(64, 3), V(64, 4), V(64, 5), V(64, 6), V(64, 8), V(64, 10), V(64, 12), V(64, 14), V(64, 16), V(64, 24), V(64, 32),
+// instances: (G, W, wavefronts per SIMD the register allocation is held to)
+#define V(G, W, OCC) {G, W, (const void*)k_pairhmm3<G, W, OCC>, 0}
+static pair_variant k_variants[] = {
+    V(16, 2, 4), V(16, 3, 4), V(16, 4, 4), V(16, 5, 4), V(16, 6, 3), V(16, 7, 3), V(16, 8, 3), V(16, 10, 3), V(16, 11, 2), V(16, 12, 2), V(16, 14, 2), V(16, 16, 2),
+    V(32, 2, 4), V(32, 3, 4), V(32, 4, 4), V(32, 5, 4), V(32, 6, 4), V(32, 7, 4), V(32, 8, 3), V(32, 10, 3), V(32, 12, 2), V(32, 14, 2), V(32, 16, 2),
+    V(64, 1, 4), V(64, 2, 4), V(64, 3, 4), V(64, 4, 4), V(64, 5, 4), V(64, 6, 4), V(64, 7, 4), V(64, 8, 3), V(64, 10, 3), V(64, 12, 3), V(64, 14, 2), V(64, 16, 2), V(64, 24, 1), V(64, 32, 1),
 };
 #undef V
-#undef V2
-
-static uint32_t max_waves() {  // persistent wavefronts: 256 CUs x 4 SIMDs x waves per SIMD (DAFS_HIP_WAVES_PER_SIMD, default 2)
-  const char* e = getenv("DAFS_HIP_WAVES_PER_SIMD");
-  const int w = e ? atoi(e) : 2;
-  return 1024u * (uint32_t)(w < 1 ? 1 : (w > 8 ? 8 : w));
-}
+static const int k_nvariants = (int)(sizeof k_variants / sizeof k_variants[0]);
 
 }  // namespace dafs
 
@@ -259,42 +278,23 @@ using namespace dafs;
 
 extern "C" int dafs_hipk_pairhmm_plan(uint32_t ntasks, uint32_t max_len1, uint32_t max_len2, dafs_pairhmm_plan* plan) {
   if (!plan || ntasks == 0 || max_len1 == 0 || max_len2 == 0) return DAFS_HIP_EINVAL;
-  const variant* best = nullptr;
-  double best_cost = 0;
-  // DAFS_HIP_FORCE_GROUP=16|32|64 pins the lanes-per-pair choice (tests exercise every variant)
-  const char* force = getenv("DAFS_HIP_FORCE_GROUP");
-  const int force_g = force ? atoi(force) : 0;
-  for (const variant& v : k_variants) {
-    if ((uint64_t)v.G * v.W < (uint64_t)max_len2 + 1) continue;
-    if (force_g && v.G != force_g) continue;
-    const uint64_t waves = ((uint64_t)ntasks + (64 / v.G) - 1) / (64 / v.G);
-    const uint64_t rounds = (waves + max_waves() - 1) / max_waves();
-    const double cost = (double)(max_len1 + v.G) * v.W * (double)rounds;
-    if (!best || cost < best_cost) { best = &v; best_cost = cost; }
-  }
-  if (!best) return DAFS_HIP_ETOOLONG;
-  const uint64_t waves = ((uint64_t)ntasks + (64 / best->G) - 1) / (64 / best->G);
-  plan->group = best->G;
-  plan->width = best->W;
-  uint32_t nw = (uint32_t)(waves < max_waves() ? waves : max_waves());
-  nw = (nw + 3) & ~3u;  // whole workgroups of 4 waves
-  plan->nwaves = nw;
-  plan->slab_steps = max_len1 + best->G;
-  plan->scratch_bytes = (uint64_t)nw * plan->slab_steps * best->W * 64 * sizeof(float);
-  return DAFS_HIP_OK;
+  // instruction counts of the four sweeps together, from the ISA of the W = 5 / 6 instances
+  return pair_choose(k_variants, k_nvariants, ntasks, max_len1, max_len2, 1, 150.0, 240.0, plan);
 }
 
 extern "C" int dafs_hipk_pairhmm3_launch(const dafs_pairhmm3_args* args, const dafs_pairhmm_plan* plan, void* hip_stream) {
   if (!args || !plan) return DAFS_HIP_EINVAL;
   if (args->ntasks == 0) return DAFS_HIP_OK;
-  const variant* v = nullptr;
-  for (const variant& c : k_variants)
+  const pair_variant* v = nullptr;
+  for (const pair_variant& c : k_variants)
     if (c.G == (int)plan->group && c.W == (int)plan->width) v = &c;
   if (!v || plan->nwaves % 4) return DAFS_HIP_EINVAL;
   const uint32_t rp_cap = plan->slab_steps - plan->group + 1;  // max_len1 + 1 row pointers
   const size_t lds = (size_t)4 * (64 / v->G) * rp_cap * sizeof(uint32_t);
   if (lds > 60 * 1024) return DAFS_HIP_ETOOLONG;
-  const char* alt = getenv("DAFS_HIP_PC_SELECT");  // tuning switch: coefficient selects instead of the LDS table
-  hipLaunchKernelGGL((alt && atoi(alt) && v->fn_alt) ? v->fn_alt : v->fn, dim3(plan->nwaves / 4), dim3(256), lds, (hipStream_t)hip_stream, *args, plan->slab_steps, rp_cap);
-  return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
+  dafs_pairhmm3_args a = *args;
+  uint32_t steps = plan->slab_steps, cap = rp_cap;
+  void* params[] = {&a, &steps, &cap};
+  if (hip_check(hipLaunchKernel(v->fn, dim3(plan->nwaves / 4), dim3(256), params, lds, (hipStream_t)hip_stream))) return DAFS_HIP_ELAUNCH;
+  return DAFS_HIP_OK;
 }

@@ -28,34 +28,36 @@ namespace dafs {
 
 enum { cM = 0, cIX = 1, cIY = 2, cI2X = 3, cI2Y = 4 };
 
-template <int G, int W>
-__global__ __launch_bounds__(256) void k_pairhmm5(dafs_pairhmm5_args a, uint32_t slab_steps, uint32_t rp_cap) {
+template <int G, int W, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_pairhmm5(dafs_pairhmm5_args a, uint32_t slab_steps, uint32_t rp_cap) {
   constexpr int NG = 64 / G;
   extern __shared__ uint32_t s_dyn[];
-  __shared__ float s_match[25], s_insert[5], s_single[5], s_pair[25];
+  __shared__ float s_match[25], s_insert[5];
   __shared__ contra_tables s_ct;
   contra_tables_init(&s_ct, threadIdx.x);
-  if (threadIdx.x < 25) { s_match[threadIdx.x] = (&a.model.match[0][0])[threadIdx.x]; s_pair[threadIdx.x] = (&a.model.pair[0][0])[threadIdx.x]; }
-  if (threadIdx.x < 5) { s_insert[threadIdx.x] = a.model.insert[threadIdx.x]; s_single[threadIdx.x] = a.model.single[threadIdx.x]; }
+  if (threadIdx.x < 25) s_match[threadIdx.x] = (&a.model.match[0][0])[threadIdx.x];
+  if (threadIdx.x < 5) s_insert[threadIdx.x] = a.model.insert[threadIdx.x];
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int t = lane % G;
   const int g = lane / G;
   const int wave_in_wg = threadIdx.x >> 6;
-  const uint32_t wave = blockIdx.x * 4 + wave_in_wg;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave_in_wg);  // scalar slab base, see pairhmm3.hip
   const size_t plane = (size_t)slab_steps * W * 64;
   float* __restrict__ slab = a.scratch + (size_t)wave * plane * 5;
   uint32_t* __restrict__ s_rowptr = s_dyn + (size_t)(wave_in_wg * NG + g) * rp_cap;
   const float NI = CONTRA_NEG_INF;
   const float th = a.th;
-  // transition scores into each state, by source state (InferenceEngine.ipp:139-226)
-  const float pMM = s_pair[cM * 5 + cM], pXM = s_pair[cIX * 5 + cM], pYM = s_pair[cIY * 5 + cM], p2XM = s_pair[cI2X * 5 + cM], p2YM = s_pair[cI2Y * 5 + cM];
-  const float pMX = s_pair[cM * 5 + cIX], pXX = s_pair[cIX * 5 + cIX], pYX = s_pair[cIY * 5 + cIX];
-  const float pMY = s_pair[cM * 5 + cIY], pXY = s_pair[cIX * 5 + cIY], pYY = s_pair[cIY * 5 + cIY];
-  const float pM2X = s_pair[cM * 5 + cI2X], p2X2X = s_pair[cI2X * 5 + cI2X], p2Y2X = s_pair[cI2Y * 5 + cI2X];
-  const float pM2Y = s_pair[cM * 5 + cI2Y], p2X2Y = s_pair[cI2X * 5 + cI2Y], p2Y2Y = s_pair[cI2Y * 5 + cI2Y];
-  const float sgM = s_single[cM], sgX = s_single[cIX], sgY = s_single[cIY], sg2X = s_single[cI2X], sg2Y = s_single[cI2Y];
+  // transition scores into each state, by source state (InferenceEngine.ipp:139-226): read from the kernel
+  // arguments, so they live in scalar registers (from LDS they would take twenty-two vector registers)
+  const float (*pr)[5] = a.model.pair;
+  const float pMM = pr[cM][cM], pXM = pr[cIX][cM], pYM = pr[cIY][cM], p2XM = pr[cI2X][cM], p2YM = pr[cI2Y][cM];
+  const float pMX = pr[cM][cIX], pXX = pr[cIX][cIX], pYX = pr[cIY][cIX];
+  const float pMY = pr[cM][cIY], pXY = pr[cIX][cIY], pYY = pr[cIY][cIY];
+  const float pM2X = pr[cM][cI2X], p2X2X = pr[cI2X][cI2X], p2Y2X = pr[cI2Y][cI2X];
+  const float pM2Y = pr[cM][cI2Y], p2X2Y = pr[cI2X][cI2Y], p2Y2Y = pr[cI2Y][cI2Y];
+  const float sgM = a.model.single[cM], sgX = a.model.single[cIX], sgY = a.model.single[cIY], sg2X = a.model.single[cI2X], sg2Y = a.model.single[cI2Y];
 
   for (;;) {
     uint32_t base = 0;
@@ -73,20 +75,24 @@ __global__ __launch_bounds__(256) void k_pairhmm5(dafs_pairhmm5_args a, uint32_t
     int maxL1 = L1;
 #pragma unroll
     for (int o = G; o < 64; o <<= 1) maxL1 = max(maxL1, __shfl_xor(maxL1, o));
-    const int nsteps = maxL1 + G;
-    const int tlast = (L2 >= 0 ? L2 : 0) / W;
+    const int nsteps = __builtin_amdgcn_readfirstlane(maxL1) + G;
+    const int wr = pair_width<G, W>(L2);  // columns per lane of this wave: W or W-1 (pair_sweeps.h)
+    const bool full = wr == W;
+    const int j0 = t * wr;
+    const int tlast = (L2 >= 0 ? L2 : 0) / wr;
 
     // y symbols of this lane's columns: cc[c] = y[j], j = t*W + c (CONTRAlign alphabet "ACGU", else 4)
     int cc[W + 1];
 #pragma unroll
     for (int c = 0; c <= W; ++c) {
-      const int j = t * W + c;
+      const int j = j0 + c;
       const int code = (j >= 1 && j <= L2) ? (int)s2[j - 1] : 4;
       cc[c] = code < 4 ? code : 4;
     }
 
     // ------------------------------------------------------------------ sweep 1: forward (:999-1070)
     float Z = NI;
+    float eM = NI, eX = NI, eY = NI, e2X = NI, e2Y = NI;
     {
       float pM[W], pX[W], pY[W], p2X[W], p2Y[W];  // row i-1 of this lane's columns
 #pragma unroll
@@ -106,7 +112,8 @@ __global__ __launch_bounds__(256) void k_pairhmm5(dafs_pairhmm5_args a, uint32_t
         const float bix = insx + sgX, bi2x = insx + sg2X;            // ScoreInsertX / ScoreInsert2X without the pair term
 #pragma unroll
         for (int c = 0; c < W; ++c) {
-          const int j = t * W + c;
+          if (!(c < W - 1 || full)) continue;
+          const int j = j0 + c;
           const bool v = rowv && (j <= L2);
           const int yj = cc[c];
           const float insy = 0.0f + s_insert[yj];
@@ -150,20 +157,25 @@ __global__ __launch_bounds__(256) void k_pairhmm5(dafs_pairhmm5_args a, uint32_t
           pM[c] = m; pX[c] = x; pY[c] = y; p2X[c] = x2; p2Y[c] = y2;
           lM = m; lX = x; lY = y; l2X = x2; l2Y = y2;
           if (v && i >= 1 && j >= 1) {
-            const size_t idx = (size_t)(s * W + c) * 64 + lane;
-            slab[idx] = aM; slab[plane + idx] = aX; slab[2 * plane + idx] = aY; slab[3 * plane + idx] = a2X; slab[4 * plane + idx] = a2Y;
-          }
-          if (v && i == L1 && j == L2) {  // ComputeForwardLogPartitionCoefficient, :1164-1170
-            float z = m;
-            z = contra_lpe(z, x); z = contra_lpe(z, y); z = contra_lpe(z, x2); z = contra_lpe(z, y2);
-            Z = z;
+            float* __restrict__ q = slab + (size_t)s * (W * 64) + (c * 64 + lane);
+            q[0] = aM; q[plane] = aX; q[2 * plane] = aY; q[3 * plane] = a2X; q[4 * plane] = a2Y;
           }
         }
         dgM = rM; dgX = rX; dgY = rY; dg2X = r2X; dg2Y = r2Y;
-        lsM = pM[W - 1]; lsX = pX[W - 1]; lsY = pY[W - 1]; ls2X = p2X[W - 1]; ls2Y = p2Y[W - 1];
+        lsM = lM; lsX = lX; lsY = lY; ls2X = l2X; ls2Y = l2Y;
+        if (i == L1 && t == tlast) {  // the five F_k(L1, L2): one lane of the group, once
+          const int cl = L2 - j0;
+#pragma unroll
+          for (int c = 0; c < W; ++c)
+            if (c == cl) { eM = pM[c]; eX = pX[c]; eY = pY[c]; e2X = p2X[c]; e2Y = p2Y[c]; }
+        }
       }
     }
-    Z = __shfl(Z, g * G + tlast);
+    {  // ComputeForwardLogPartitionCoefficient, :1164-1170
+      float z = eM;
+      z = contra_lpe(z, eX); z = contra_lpe(z, eY); z = contra_lpe(z, e2X); z = contra_lpe(z, e2Y);
+      Z = __shfl(z, g * G + tlast);
+    }
 
     // ------------------------------------------------------------------ sweep 2: backward (:1079-1150) + posterior (:1279-1317)
     {
@@ -173,9 +185,10 @@ __global__ __launch_bounds__(256) void k_pairhmm5(dafs_pairhmm5_args a, uint32_t
       float fsM = NI, fsY = NI, fs2Y = NI;  // this lane's first column, row of the previous step
       float dgM = NI;                       // right neighbour's first column, one row later
       for (int s = 0; s < nsteps; ++s) {
-        const int i = L1 - s + (G - 1 - t);
+        const int sf = nsteps - 1 - s;  // forward step of row i for this lane: wave-uniform (pairhmm3.hip, sweep 2)
+        const int i = sf - t;
         const bool rowv = (i >= 1) && (i <= L1);
-        const int sf = i + t;
+        float* __restrict__ slab_s = slab + (size_t)sf * (W * 64);
         int xn = (rowv && i < L1) ? (int)s1[i] : 4;  // x[i+1]
         xn = xn < 4 ? xn : 4;
         const float rM = shift_down1<G>(fsM, NI, t), rY = shift_down1<G>(fsY, NI, t), r2Y = shift_down1<G>(fs2Y, NI, t);
@@ -186,15 +199,16 @@ __global__ __launch_bounds__(256) void k_pairhmm5(dafs_pairhmm5_args a, uint32_t
         float ak[5][W];
 #pragma unroll
         for (int c = 0; c < W; ++c) {
-          const int j = t * W + c;
+          if (!(c < W - 1 || full)) continue;
+          const int j = j0 + c;
           const bool v = rowv && j >= 1 && j <= L2;
-          const size_t idx = (size_t)(sf * W + c) * 64 + lane;
 #pragma unroll
-          for (int k = 0; k < 5; ++k) ak[k][c] = v ? slab[k * plane + idx] : 0.0f;
+          for (int k = 0; k < 5; ++k) ak[k][c] = v ? slab_s[k * plane + (c * 64 + lane)] : 0.0f;
         }
 #pragma unroll
         for (int c = W - 1; c >= 0; --c) {
-          const int j = t * W + c;
+          if (!(c < W - 1 || full)) continue;
+          const int j = j0 + c;
           const bool v = rowv && j >= 1 && j <= L2;
           const int yn = cc[c + 1];  // y[j+1]
           const float insy = 0.0f + s_insert[yn];
@@ -230,7 +244,7 @@ __global__ __launch_bounds__(256) void k_pairhmm5(dafs_pairhmm5_args a, uint32_t
               p += e4.x;
             }
             const float mx = p < 0.0f ? 0.0f : p;
-            slab[(size_t)(sf * W + c) * 64 + lane] = (1.0f < mx) ? 1.0f : mx;
+            slab_s[c * 64 + lane] = (1.0f < mx) ? 1.0f : mx;
           }
           if (c == 0) { fsY = bY; fs2Y = b2Y; }
         }
@@ -239,20 +253,18 @@ __global__ __launch_bounds__(256) void k_pairhmm5(dafs_pairhmm5_args a, uint32_t
       }
     }
     // row 0 / column 0 of plane 0 were never written: pair_finish ignores them (inner cells only)
-    pair_finish<G, W>(a, slab, s_rowptr, lane, t, g, L1, L2, nsteps, tlast, act, task, th, [](float sv) { return sv; });
+    pair_finish<G, W>(a, slab, s_rowptr, lane, t, g, L1, L2, nsteps, wr, act, task, th, [](float sv) { return sv; });
   }
 }
 
-typedef void (*pairhmm5_fn)(dafs_pairhmm5_args, uint32_t, uint32_t);
-struct variant5 { int G, W; pairhmm5_fn fn; };
-#define V(G, W) {G, W, k_pairhmm5<G, W>}
-static const variant5 k_variants5[] = {
-    V(16, 2), V(16, 3), V(16, 4), V(16, 5), V(16, 6), V(16, 8), V(16, 10), V(16, 11), V(16, 12),
-    V(32, 2), V(32, 3), V(32, 4), V(32, 5), V(32, 6), V(32, 8), V(32, 10), V(32, 12),
-    V(64, 1), V(64, 2), V(64, 3), V(64, 4), V(64, 5), V(64, 6), V(64, 8), V(64, 10), V(64, 12), V(64, 16),
+#define V(G, W, OCC) {G, W, (const void*)k_pairhmm5<G, W, OCC>, 0}
+static pair_variant k_variants5[] = {
+    V(16, 2, 2), V(16, 3, 2), V(16, 4, 2), V(16, 5, 2), V(16, 6, 2), V(16, 8, 2), V(16, 10, 1), V(16, 11, 1), V(16, 12, 1),
+    V(32, 2, 2), V(32, 3, 2), V(32, 4, 2), V(32, 5, 2), V(32, 6, 2), V(32, 7, 2), V(32, 8, 2), V(32, 10, 1), V(32, 12, 1),
+    V(64, 1, 2), V(64, 2, 2), V(64, 3, 2), V(64, 4, 2), V(64, 5, 2), V(64, 6, 2), V(64, 7, 2), V(64, 8, 2), V(64, 10, 1), V(64, 12, 1), V(64, 16, 1),
 };
 #undef V
-static const uint32_t kMaxWaves5 = 256 * 8;
+static const int k_nvariants5 = (int)(sizeof k_variants5 / sizeof k_variants5[0]);
 
 }  // namespace dafs
 
@@ -260,40 +272,22 @@ using namespace dafs;
 
 extern "C" int dafs_hipk_pairhmm5_plan(uint32_t ntasks, uint32_t max_len1, uint32_t max_len2, dafs_pairhmm_plan* plan) {
   if (!plan || ntasks == 0 || max_len1 == 0 || max_len2 == 0) return DAFS_HIP_EINVAL;
-  const variant5* best = nullptr;
-  double best_cost = 0;
-  const char* force = getenv("DAFS_HIP_FORCE_GROUP");
-  const int force_g = force ? atoi(force) : 0;
-  for (const variant5& v : k_variants5) {
-    if ((uint64_t)v.G * v.W < (uint64_t)max_len2 + 1) continue;
-    if (force_g && v.G != force_g) continue;
-    const uint64_t waves = ((uint64_t)ntasks + (64 / v.G) - 1) / (64 / v.G);
-    const uint64_t rounds = (waves + kMaxWaves5 - 1) / kMaxWaves5;
-    const double cost = (double)(max_len1 + v.G) * v.W * (double)rounds;
-    if (!best || cost < best_cost) { best = &v; best_cost = cost; }
-  }
-  if (!best) return DAFS_HIP_ETOOLONG;
-  const uint64_t waves = ((uint64_t)ntasks + (64 / best->G) - 1) / (64 / best->G);
-  plan->group = best->G;
-  plan->width = best->W;
-  uint32_t nw = (uint32_t)(waves < kMaxWaves5 ? waves : kMaxWaves5);
-  nw = (nw + 3) & ~3u;
-  plan->nwaves = nw;
-  plan->slab_steps = max_len1 + best->G;
-  plan->scratch_bytes = (uint64_t)nw * plan->slab_steps * best->W * 64 * sizeof(float) * 5;  // five planes
-  return DAFS_HIP_OK;
+  return pair_choose(k_variants5, k_nvariants5, ntasks, max_len1, max_len2, 5, 250.0, 560.0, plan);  // five planes
 }
 
 extern "C" int dafs_hipk_pairhmm5_launch(const dafs_pairhmm5_args* args, const dafs_pairhmm_plan* plan, void* hip_stream) {
   if (!args || !plan) return DAFS_HIP_EINVAL;
   if (args->ntasks == 0) return DAFS_HIP_OK;
-  const variant5* v = nullptr;
-  for (const variant5& c : k_variants5)
+  const pair_variant* v = nullptr;
+  for (const pair_variant& c : k_variants5)
     if (c.G == (int)plan->group && c.W == (int)plan->width) v = &c;
   if (!v || plan->nwaves % 4) return DAFS_HIP_EINVAL;
   const uint32_t rp_cap = plan->slab_steps - plan->group + 1;
   const size_t lds = (size_t)4 * (64 / v->G) * rp_cap * sizeof(uint32_t);
   if (lds > 60 * 1024) return DAFS_HIP_ETOOLONG;
-  hipLaunchKernelGGL(v->fn, dim3(plan->nwaves / 4), dim3(256), lds, (hipStream_t)hip_stream, *args, plan->slab_steps, rp_cap);
-  return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
+  dafs_pairhmm5_args a = *args;
+  uint32_t steps = plan->slab_steps, cap = rp_cap;
+  void* params[] = {&a, &steps, &cap};
+  if (hip_check(hipLaunchKernel(v->fn, dim3(plan->nwaves / 4), dim3(256), params, lds, (hipStream_t)hip_stream))) return DAFS_HIP_ELAUNCH;
+  return DAFS_HIP_OK;
 }

@@ -67,6 +67,7 @@ struct pc_tables {
   // apart on purpose: closer, the compiler fuses the reads of one argument into ds_read2 pairs and then
   // spends moves re-pairing them by coefficient for the packed multiply-adds.
   float lk[4][260];
+  float4 lq[16];       // the cubics again, whole, in the slot order of pc_slot16: one ds_read_b128 per LOG_ADD
   double2 exp_hi[8];   // k4,k3 of the EXP quartics, index = clamp(exponent(|x|) + 2, 0, 6); [6] = zero
   double2 exp_mid[8];  // k2,k1
   double exp_lo[8];    // k0
@@ -96,11 +97,14 @@ __device__ __forceinline__ void pc_tables_init(pc_tables* t, int tid) {
   }
 }
 
-// second stage of the initialisation (after a barrier): the coefficient-wise copies
+// second stage of the initialisation (after a barrier): the coefficient-wise copies, slot (16 - k) & 15 for
+// k = ceil(2d) = 0..15 (pc_slot4); k >= 10 is the last piece
 __device__ __forceinline__ void pc_tables_init2(pc_tables* t, int tid, int nthreads) {
-  for (int e = tid; e < 12; e += nthreads) {
-    const float4 a = t->lookup[e];
+  for (int k = tid; k < 16; k += nthreads) {
+    const float4 a = t->lookup[k < 11 ? k : 11];
+    const int e = (16 - k) & 15;
     t->lk[0][e] = a.x; t->lk[1][e] = a.y; t->lk[2][e] = a.z; t->lk[3][e] = a.w;
+    t->lq[e] = a;
   }
 }
 
@@ -131,20 +135,50 @@ __device__ __forceinline__ float pc_log_add_t(const pc_tables* t, float x, float
 // v_pk_add_f32 do both lanes' multiply or add in one issue slot, and with contraction off they stay
 // separate roundings, i.e. the same operations as two calls of pc_log_add_t.
 typedef float pc_f2 __attribute__((ext_vector_type(2)));
+// Slot of the cubic for 2d in the coefficient rows: -ceil(2d) is one instruction (v_cvt_flr_i32_f32 of the negated
+// operand; floor(-x) = -ceil(x)), and its low four bits are a valid slot for every d: 0 for d = 0, 16 - ceil(2d)
+// for 0 < d < 7.5 (pc_tables_init2 lays the rows out that way), anything in 0..15 for the d >= 7.5 that the
+// caller's select throws away (LOG_ZERO operands give 4e20 and saturate the conversion).  Returns the byte offset.
+__device__ __forceinline__ unsigned pc_slot4(float d2) {
+  int k;
+  asm("v_cvt_flr_i32_f32_e64 %0, -%1" : "=v"(k) : "v"(d2));
+  return ((unsigned)k << 2) & 60u;
+}
 __device__ __forceinline__ pc_f2 pc_log_add2_t(const pc_tables* t, pc_f2 x, pc_f2 y) {
   pc_f2 lo, hi;
   lo.x = fminf(x.x, y.x); lo.y = fminf(x.y, y.y);
   hi.x = fmaxf(x.x, y.x); hi.y = fmaxf(x.y, y.y);
   const pc_f2 d = hi - lo;
-  const pc_f2 d2 = d * 2.0f;
-  const unsigned ka = (unsigned)fminf(ceilf(d2.x), 10.0f), kb = (unsigned)fminf(ceilf(d2.y), 10.0f);
-  const pc_f2 k3 = {t->lk[0][ka], t->lk[0][kb]}, k2 = {t->lk[1][ka], t->lk[1][kb]}, k1 = {t->lk[2][ka], t->lk[2][kb]}, k0 = {t->lk[3][ka], t->lk[3][kb]};
+  const pc_f2 d2 = d + d;
+  const unsigned ka = pc_slot4(d2.x), kb = pc_slot4(d2.y);
+  const char* b0 = (const char*)t->lk[0], *b1 = (const char*)t->lk[1], *b2 = (const char*)t->lk[2], *b3 = (const char*)t->lk[3];
+  const pc_f2 k3 = {*(const float*)(b0 + ka), *(const float*)(b0 + kb)}, k2 = {*(const float*)(b1 + ka), *(const float*)(b1 + kb)};
+  const pc_f2 k1 = {*(const float*)(b2 + ka), *(const float*)(b2 + kb)}, k0 = {*(const float*)(b3 + ka), *(const float*)(b3 + kb)};
   const pc_f2 r = (((k3 * d + k2) * d + k1) * d + k0) + lo;
   pc_f2 o;
   o.x = d.x >= 7.5f ? hi.x : r.x;
   o.y = d.y >= 7.5f ? hi.y : r.y;
   return o;
 }
+// LOG_ADD with one 16-byte lookup and plain (unpacked) float arithmetic.  Measured on MI355X
+// (profiles/r02_*_valu_rate.txt): with four or more wavefronts per SIMD v_add_f32 / v_mul_f32 issue at 2.5x the rate of
+// every other vector instruction, packed f32 included, and an LDS read costs its SIMD as much as 4-7 vector
+// instructions whatever its width -- so: one ds_read_b128 instead of four ds_read_b32, seven plain adds/multiplies,
+// and as few other instructions as the reference's semantics allow.
+// Slot: (-ceil(32 d)) & 0xF0 = 16 * ((-ceil(2d)) & 15) for d < 7.5 (ceil(ceil(x)/16) = ceil(x/16)), i.e. the byte offset
+// of the cubic in lq, from one conversion and one AND; d >= 7.5 lands on some valid slot and is thrown away.
+__device__ __forceinline__ float pc_log_add_q(const pc_tables* t, float x, float y) {
+  const float lo = fminf(x, y);
+  const float hi = fmaxf(x, y);
+  const float d = hi - lo;
+  const float d32 = d * 32.0f;
+  int k;
+  asm("v_cvt_flr_i32_f32_e64 %0, -%1" : "=v"(k) : "v"(d32));
+  const float4 q = *(const float4*)((const char*)t->lq + (k & 240));
+  const float r = ((q.x * d + q.y) * d + q.z) * d + q.w + lo;
+  return d >= 7.5f ? hi : r;
+}
+
 template <bool LUT>
 __device__ __forceinline__ pc_f2 pc_log_add2(const pc_tables* t, pc_f2 x, pc_f2 y) {
   if (LUT) return pc_log_add2_t(t, x, y);
