@@ -9,9 +9,9 @@
 //   sweep 4: scatter into the CSR of mp[x][y] and of mp[y][x] (src/dafs.cpp:155-167)
 //
 // Column ownership.  A kernel instance is compiled for W columns per lane, but a wavefront whose
-// pairs are short enough runs with wr = W-1 (lane t owns columns t*wr .. t*wr+wr-1): the last cell
-// of every step is then skipped by a wave-uniform branch.  Lengths inside one batch differ by a few
-// per cent (the benchmark sets: +-7 %), and with W-1 = 5 instead of 6 columns that is 17 % of the cells.
+// pairs are short enough runs the W-1 instantiation of every sweep (lane t owns columns
+// t*WR .. t*WR+WR-1, WR = W or W-1; the slab keeps stride W).  Lengths inside one batch differ by a few
+// per cent (the benchmark sets: +-7 %), and with 5 instead of 6 columns that is 17 % of the cells.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -64,25 +64,42 @@ __device__ __forceinline__ int pair_width(int L2) {
   return (m + 1 <= G * (W - 1)) ? W - 1 : W;
 }
 
-template <int G, int W, class Args, class Post>
-__device__ __forceinline__ void pair_finish(const Args& a, float* __restrict__ slab, uint32_t* __restrict__ s_rowptr, int lane, int t, int g,
-                                            int L1, int L2, int nsteps, int wr, bool act, uint32_t task, float th, Post post) {
-  const bool full = wr == W;
-  const int tlast = (L2 >= 0 ? L2 : 0) / wr;  // lane (within the group) that owns column L2
-  const int j0 = t * wr;
+// WR = columns this wave's lanes own (W or W-1, compile time here: the kernels branch once per pair on pair_width and
+// instantiate every sweep for both), W = slab stride.  post(sv, p) turns the WR slab values of a step into posteriors.
+//
+// Entries are rare (a few per row), so sweep 3 does not write the thresholded plane back for a fourth sweep over every
+// cell to re-read: each lane appends a 12-byte record per entry {p, row-1 | c<<16, position in its row | position in
+// its column << 16} to a private list (`list`: a second plane of the wave's scratch, same [k*64 + lane] layout), and
+// sweep 4 walks the lists -- a third less HBM traffic for the whole kernel, and ~40 list steps instead of ~190 grid
+// steps.  A lane whose list is full (more than a third of its cells are entries: th near 0) makes the call return
+// false with nothing emitted and the slab untouched; the caller then runs the dense = true instantiation, which is
+// the plane-and-rescan form.
+template <int G, int W, int WR, bool dense, class Args, class Post>
+__device__ __forceinline__ bool pair_finish(const Args& a, float* __restrict__ slab, float* __restrict__ list, int list_cap, uint32_t* __restrict__ s_rowptr,
+                                            int lane, int t, int g, int L1, int L2, int nsteps, bool act, uint32_t task, float th, Post post) {
+  const int tlast = (L2 >= 0 ? L2 : 0) / WR;  // lane (within the group) that owns column L2
+  const int j0 = t * WR;
   // ------------------------------------------------------------------ sweep 3: posterior + sim + counts
-  int colcnt[W];
+  int colcnt[WR];
   float simv = 0.0f;
   uint32_t nnz = 0;
+  int slab_nrec = 0;
   {
-    float pdp[W];
-    int ptr[W];
+    float pdp[WR];
+    int ptr[WR];
 #pragma unroll
-    for (int c = 0; c < W; ++c) { pdp[c] = 0.0f; ptr[c] = 0; colcnt[c] = 0; }
+    for (int c = 0; c < WR; ++c) { pdp[c] = 0.0f; ptr[c] = 0; colcnt[c] = 0; }
     float lastdp = 0.0f, dgdp = 0.0f;
     int lasttr = 0, dgtr = 0, lastcnt = 0;
     uint32_t rowacc = 0;
     if (t == G - 1) s_rowptr[0] = 0;
+    int nrec = 0;       // records in this lane's list
+    bool ovf = false;
+    // slab values are fetched one step ahead (a load issued where it is needed waits for itself and for the stores of
+    // the step before: loads and stores share one in-order counter)
+    float sv[WR];
+#pragma unroll
+    for (int c = 0; c < WR; ++c) sv[c] = slab[c * 64 + lane];
     for (int s = 0; s < nsteps; ++s) {
       const int i = s - t;
       const bool rowv = (i >= 0) && (i <= L1);
@@ -91,49 +108,63 @@ __device__ __forceinline__ void pair_finish(const Args& a, float* __restrict__ s
       const int rtr = shift_up1<G>(lasttr, 0, t), rcnt = shift_up1<G>(lastcnt, 0, t);
       float ddp = dgdp, ldp = rdp;
       int dtr = dgtr, ltr = rtr, run = rcnt;
-      float sv[W];
+      float pp[WR];
+      post(sv, pp);  // the model's posteriors of the WR cells, table reads batched
+      if (s + 1 < nsteps) {
 #pragma unroll
-      for (int c = 0; c < W; ++c) {
-        if (c < W - 1 || full) sv[c] = slab_s[c * 64 + lane];  // private slot: unguarded (cells outside the grid are ignored below)
+        for (int c = 0; c < WR; ++c) sv[c] = slab_s[(W + c) * 64 + lane];  // private slots: unguarded (cells outside the grid are ignored below)
       }
 #pragma unroll
-      for (int c = 0; c < W; ++c) {
-        if (c < W - 1 || full) {
-          const int j = j0 + c;
-          const bool v = rowv && (j <= L2);
-          const bool inner = v && i >= 1 && j >= 1;
-          // the model's posterior; wrapper (>= th keeps) then adapter (> th keeps): align.cpp:69-78
-          const float p = post(sv[c]);
-          const bool entry = inner && (p >= th) && (p > th);
+      for (int c = 0; c < WR; ++c) {
+        const int j = j0 + c;
+        const bool v = rowv && (j <= L2);
+        const bool inner = v && i >= 1 && j >= 1;
+        // wrapper (>= th keeps) then adapter (> th keeps): align.cpp:69-78
+        const float p = pp[c];
+        const bool entry = inner && (p >= th) && (p > th);
+        if (dense) {
           slab_s[c * 64 + lane] = entry ? p : 0.0f;
-          // calculate_similarity_score, dafs.cpp:720-760
-          const float udp = pdp[c];
-          const int utr = ptr[c];
-          float dp;
-          int tr;
-          if (entry) {
-            dp = ddp + p; tr = dtr + 1;
-            if (dp < ldp) { dp = ldp; tr = ltr + 1; }
-            if (dp < udp) { dp = udp; tr = utr + 1; }
+        } else if (entry) {
+          if (3 * nrec + 3 <= list_cap) {
+            float* __restrict__ r = list + (size_t)(3 * nrec) * 64 + lane;
+            r[0] = p;
+            r[64] = __int_as_float((i - 1) | (c << 16));
+            r[128] = __int_as_float(run | (colcnt[c] << 16));
+            ++nrec;
           } else {
-            dp = ldp; tr = ltr + 1;
-            if (dp < udp) { dp = udp; tr = utr + 1; }
+            ovf = true;
           }
-          if (!inner) { dp = 0.0f; tr = 0; }
-          ddp = udp; dtr = utr;
-          pdp[c] = dp; ptr[c] = tr;
-          ldp = dp; ltr = tr;
-          run += entry ? 1 : 0;
-          colcnt[c] += entry ? 1 : 0;
         }
+        // calculate_similarity_score, dafs.cpp:720-760
+        const float udp = pdp[c];
+        const int utr = ptr[c];
+        float dp;
+        int tr;
+        if (entry) {
+          dp = ddp + p; tr = dtr + 1;
+          if (dp < ldp) { dp = ldp; tr = ltr + 1; }
+          if (dp < udp) { dp = udp; tr = utr + 1; }
+        } else {
+          dp = ldp; tr = ltr + 1;
+          if (dp < udp) { dp = udp; tr = utr + 1; }
+        }
+        if (!inner) { dp = 0.0f; tr = 0; }
+        ddp = udp; dtr = utr;
+        pdp[c] = dp; ptr[c] = tr;
+        ldp = dp; ltr = tr;
+        run += entry ? 1 : 0;
+        colcnt[c] += entry ? 1 : 0;
       }
       dgdp = rdp; dgtr = rtr;
       lastdp = ldp; lasttr = ltr; lastcnt = run;
       if (i == L1 && t == tlast) {  // dafs.cpp:763; one lane of the group, once
         const int cl = L2 - j0;
+        float sdp = 0.0f;
+        int str = 1;
 #pragma unroll
-        for (int c = 0; c < W; ++c)
-          if (c == cl) simv = pdp[c] / (float)ptr[c];
+        for (int c = 0; c < WR; ++c)
+          if (c == cl) { sdp = pdp[c]; str = ptr[c]; }
+        simv = sdp / (float)str;
       }
       if (t == G - 1 && rowv && i >= 1) {  // row i is complete: its count has crossed the group
         rowacc += (uint32_t)run;
@@ -141,16 +172,18 @@ __device__ __forceinline__ void pair_finish(const Args& a, float* __restrict__ s
       }
     }
     nnz = rowacc;
+    if (!dense && __any(ovf)) return false;  // wave-uniform: every pair of the wave takes the dense form
+    slab_nrec = nrec;
   }
   nnz = __shfl(nnz, g * G + (G - 1));
   simv = __shfl(simv, g * G + tlast);
 
   // column prefix sums (row pointers of the transposed matrix)
-  int colbase[W];
+  int colbase[WR];
   {
     int mine = 0;
 #pragma unroll
-    for (int c = 0; c < W; ++c) mine += colcnt[c];
+    for (int c = 0; c < WR; ++c) mine += colcnt[c];
     int incl = mine;
 #pragma unroll
     for (int o = 1; o < G; o <<= 1) {
@@ -159,7 +192,7 @@ __device__ __forceinline__ void pair_finish(const Args& a, float* __restrict__ s
     }
     int run = incl - mine;
 #pragma unroll
-    for (int c = 0; c < W; ++c) { colbase[c] = run; run += colcnt[c]; }
+    for (int c = 0; c < WR; ++c) { colbase[c] = run; run += colcnt[c]; }
   }
 
   // reserve 2*nnz entries in the pool
@@ -180,50 +213,80 @@ __device__ __forceinline__ void pair_finish(const Args& a, float* __restrict__ s
     for (int r = t; r <= L1; r += G) a.rowptr_pool[rp + r] = s_rowptr[r];
     if (t == 0) a.rowptr_pool[rp + L1 + 1] = 0;
 #pragma unroll
-    for (int c = 0; c < W; ++c) {
+    for (int c = 0; c < WR; ++c) {
       const int j = j0 + c;
-      if ((c < W - 1 || full) && j >= 1 && j <= L2) a.rowptr_pool[rp + L1 + 1 + j] = (uint32_t)(colbase[c] + colcnt[c]);
+      if (j >= 1 && j <= L2) a.rowptr_pool[rp + L1 + 1 + j] = (uint32_t)(colbase[c] + colcnt[c]);
     }
   }
 
   // ------------------------------------------------------------------ sweep 4: emit CSR + transposed CSR
-  if (__any(ok)) {
-    int colrun[W];
+  if (!dense) {
+    if (__any(ok)) {
+      int maxrec = slab_nrec;
 #pragma unroll
-    for (int c = 0; c < W; ++c) colrun[c] = 0;
+      for (int o = 1; o < 64; o <<= 1) maxrec = max(maxrec, __shfl_xor(maxrec, o));
+      maxrec = __builtin_amdgcn_readfirstlane(maxrec);
+      float rp = 0.0f;
+      int r1 = 0, r2 = 0;
+      if (slab_nrec > 0) { rp = list[lane]; r1 = __float_as_int(list[64 + lane]); r2 = __float_as_int(list[128 + lane]); }
+      for (int k = 0; k < maxrec; ++k) {
+        const bool live = k < slab_nrec;
+        const float p = rp;
+        const int q1 = r1, q2 = r2;
+        if (k + 1 < slab_nrec) {  // next record, one iteration ahead
+          const float* __restrict__ r = list + (size_t)(3 * (k + 1)) * 64 + lane;
+          rp = r[0]; r1 = __float_as_int(r[64]); r2 = __float_as_int(r[128]);
+        }
+        if (live && ok) {
+          const int im1 = q1 & 0xFFFF, c = q1 >> 16;
+          int cb = 0;
+#pragma unroll
+          for (int cc = 0; cc < WR; ++cc) cb = (c == cc) ? colbase[cc] : cb;
+          const unsigned long long pos = off + s_rowptr[im1] + (uint32_t)(q2 & 0xFFFF);
+          a.ent_col[pos] = (uint32_t)(j0 + c - 1);
+          a.ent_val[pos] = p;
+          const unsigned long long tpos = off + nnz + (uint32_t)(cb + (q2 >> 16));
+          a.ent_col[tpos] = (uint32_t)im1;
+          a.ent_val[tpos] = p;
+        }
+      }
+    }
+  } else if (__any(ok)) {
+    int colrun[WR];
+#pragma unroll
+    for (int c = 0; c < WR; ++c) colrun[c] = 0;
     int lastcnt = 0;
+    float pv[WR];
+#pragma unroll
+    for (int c = 0; c < WR; ++c) pv[c] = slab[c * 64 + lane];
     for (int s = 0; s < nsteps; ++s) {
       const int i = s - t;
       const bool rowv = (i >= 0) && (i <= L1);
-      const float* __restrict__ slab_s = slab + (size_t)s * (W * 64);
+      const float* slab_s = slab + (size_t)s * (W * 64);
       int run = shift_up1<G>(lastcnt, 0, t);
       const uint32_t rowbase = (rowv && i >= 1) ? s_rowptr[i - 1] : 0;
-      float pv[W];
 #pragma unroll
-      for (int c = 0; c < W; ++c) {
-        if (c < W - 1 || full) pv[c] = slab_s[c * 64 + lane];  // sweep 3 left 0 in every non-entry slot
-      }
-#pragma unroll
-      for (int c = 0; c < W; ++c) {
-        if (c < W - 1 || full) {
-          const int j = j0 + c;
-          const bool entry = pv[c] != 0.0f;
-          if (entry && ok) {
-            const unsigned long long pos = off + rowbase + (uint32_t)run;
-            a.ent_col[pos] = (uint32_t)(j - 1);
-            a.ent_val[pos] = pv[c];
-            const unsigned long long tpos = off + nnz + (uint32_t)(colbase[c] + colrun[c]);
-            a.ent_col[tpos] = (uint32_t)(i - 1);
-            a.ent_val[tpos] = pv[c];
-          }
-          run += entry ? 1 : 0;
-          colrun[c] += entry ? 1 : 0;
+      for (int c = 0; c < WR; ++c) {
+        const int j = j0 + c;
+        const float p = pv[c];  // sweep 3 left 0 in every non-entry slot
+        if (s + 1 < nsteps) pv[c] = slab_s[(W + c) * 64 + lane];
+        const bool entry = p != 0.0f;
+        if (entry && ok) {
+          const unsigned long long pos = off + rowbase + (uint32_t)run;
+          a.ent_col[pos] = (uint32_t)(j - 1);
+          a.ent_val[pos] = p;
+          const unsigned long long tpos = off + nnz + (uint32_t)(colbase[c] + colrun[c]);
+          a.ent_col[tpos] = (uint32_t)(i - 1);
+          a.ent_val[tpos] = p;
         }
+        run += entry ? 1 : 0;
+        colrun[c] += entry ? 1 : 0;
       }
       lastcnt = run;
     }
   }
   wave_lds_fence();
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -233,6 +296,7 @@ struct pair_variant {
   int G, W;
   const void* fn;   // kernel entry (hipFuncGetAttributes / launch)
   int vgprs;        // registers per lane of the code object (0 until queried)
+  int occ;          // wavefronts per SIMD the instance was compiled for (__launch_bounds__): stands in without a device
 };
 
 // waves per SIMD the register file allows (MI355X_MICROARCH.md, register files: 512 per lane per SIMD, granule 8)
@@ -242,12 +306,13 @@ inline int pair_occupancy(int vgprs) {
   return w < 1 ? 1 : w;
 }
 
-// Picks (G, W) and the number of persistent wavefronts.  The model: a wavefront executes
-// (max_len1 + G) steps of (step_cost + W * cell_cost) instructions; a SIMD that holds `occ` wavefronts at
-// once issues one vector instruction every 2 cycles when enough of them are ready and a lone wavefront one
-// every ~12 (its own issue rate plus the LDS-lookup latency in every log-sum-exp), so a SIMD with n wavefronts
-// to run needs  work * max(12 * ceil(n / occ), 2.6 * n)  cycles.  occ comes from the code object's register
-// count (hipFuncGetAttributes), not from a guess.
+// Picks (G, W) and the number of persistent wavefronts.  The model, fitted to runs of the ProbCons kernel on MI355X
+// (profiles/r02_b_variants.txt): a wavefront executes (max_len1 + G) steps, each worth step_cost + cell_cost * (W - 1/2)
+// ns of its SIMD's issue time (most waves of a batch run the W-1 instantiation); a SIMD that holds k wavefronts at
+// once works at eff(k) = 0.5 / 0.75 / 1 of its issue rate for k = 1 / 2 / 3 or more (the sweeps wait on LDS lookups
+// and on their slab); whole-wave groups spend 0.83 of that per step (no seam, uniform pair bounds); and when the
+// batch needs r > 1 rounds of resident wavefronts the rounds overlap each other's memory-bound and issue-bound
+// sweeps (x 1 - 0.17 (1 - 1/r)).  k comes from the code object's register count (hipFuncGetAttributes), not from a guess.
 inline int pair_choose(pair_variant* vs, int nv, uint32_t ntasks, uint32_t max_len1, uint32_t max_len2, int planes,
                        double step_cost, double cell_cost, dafs_pairhmm_plan* plan) {
   int cus = 256, dev = 0;
@@ -272,16 +337,17 @@ inline int pair_choose(pair_variant* vs, int nv, uint32_t ntasks, uint32_t max_l
     if (v.vgprs == 0) {
       hipFuncAttributes at;
       if (hipFuncGetAttributes(&at, v.fn) == hipSuccess && at.numRegs > 0) v.vgprs = at.numRegs;
-      else { (void)hipGetLastError(); v.vgprs = 88 + 8 * v.W; }
+      else { (void)hipGetLastError(); v.vgprs = 512 / v.occ / 8 * 8; }
     }
     int occ = pair_occupancy(v.vgprs);
     if (cap_occ > 0 && occ > cap_occ) occ = cap_occ;
     const uint64_t waves = ((uint64_t)ntasks + (64 / v.G) - 1) / (64 / v.G);
-    const double n = (double)waves / (4.0 * cus);
-    const double rounds = (double)((waves + (uint64_t)occ * 4 * cus - 1) / ((uint64_t)occ * 4 * cus));
-    const double work = (double)(max_len1 + v.G) * (step_cost + v.W * cell_cost);
-    const double a = 12.0 * rounds, b = 2.6 * n;
-    const double cost = work * (a > b ? a : b);
+    const double n = (double)waves / (4.0 * cus);  // wavefronts per SIMD over the whole batch
+    const double k = n < 1.0 ? 1.0 : (n < occ ? n : (double)occ);  // resident at once
+    const double eff = k < 1.5 ? 0.5 : (k < 2.5 ? 0.75 : 1.0);
+    const double step = (step_cost + cell_cost * (v.W - 0.5)) * (v.G == 64 ? 0.83 : 1.0);
+    const double rounds = n > occ ? n / occ : 1.0;
+    const double cost = (double)(max_len1 + v.G) * step * (n < 1.0 ? 1.0 : n) / eff * (1.0 - 0.17 * (1.0 - 1.0 / rounds));
     if (!best || cost < best_cost) { best = &v; best_cost = cost; best_occ = occ; }
   }
   if (!best) return DAFS_HIP_ETOOLONG;

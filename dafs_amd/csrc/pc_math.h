@@ -58,16 +58,11 @@ __device__ __forceinline__ float pc_exp(float xf) {
   return (float)((((k4 * x + k3) * x + k2) * x + k1) * x + k0);
 }
 
-// ---- table-driven forms: same polynomials, coefficients fetched from LDS by one ds_read_b128
-// instead of a dozen selects.  pc_tables lives in LDS, filled by pc_tables_init.
+// ---- table-driven forms: same polynomials, coefficients fetched from LDS.  pc_tables lives in LDS, filled by
+// pc_tables_init (thread 0) + pc_tables_init2 (after a barrier).
 struct pc_tables {
   float4 lookup[12];   // LOOKUP cubic (k3,k2,k1,k0) valid on ((k-1)/2, k/2], k = min(ceil(2x), 10)
-  // the same cubics coefficient by coefficient (lk[0] = k3 ... lk[3] = k0): lanes that differ in k hit
-  // different banks, lanes that agree broadcast, so the reads are conflict-free.  The rows are 1040 bytes
-  // apart on purpose: closer, the compiler fuses the reads of one argument into ds_read2 pairs and then
-  // spends moves re-pairing them by coefficient for the packed multiply-adds.
-  float lk[4][260];
-  float4 lq[16];       // the cubics again, whole, in the slot order of pc_slot16: one ds_read_b128 per LOG_ADD
+  float4 lq[16];       // the same cubics in the slot order of pc_log_add_n, for arguments scaled by 32: one ds_read_b128 per LOG_ADD
   double2 exp_hi[8];   // k4,k3 of the EXP quartics, index = clamp(exponent(|x|) + 2, 0, 6); [6] = zero
   double2 exp_mid[8];  // k2,k1
   double exp_lo[8];    // k0
@@ -97,14 +92,12 @@ __device__ __forceinline__ void pc_tables_init(pc_tables* t, int tid) {
   }
 }
 
-// second stage of the initialisation (after a barrier): the coefficient-wise copies, slot (16 - k) & 15 for
-// k = ceil(2d) = 0..15 (pc_slot4); k >= 10 is the last piece
+// second stage of the initialisation (after a barrier): slot (16 - k) & 15 holds the cubic of k = ceil(2d) = 0..15
+// (k >= 10 is the last piece), rescaled for the 32x domain of pc_log_add_n (powers of two: exact)
 __device__ __forceinline__ void pc_tables_init2(pc_tables* t, int tid, int nthreads) {
   for (int k = tid; k < 16; k += nthreads) {
     const float4 a = t->lookup[k < 11 ? k : 11];
-    const int e = (16 - k) & 15;
-    t->lk[0][e] = a.x; t->lk[1][e] = a.y; t->lk[2][e] = a.z; t->lk[3][e] = a.w;
-    t->lq[e] = a;
+    t->lq[(16 - k) & 15] = make_float4(a.x * (1.0f / 1024.0f), a.y * (1.0f / 32.0f), a.z, a.w * 32.0f);
   }
 }
 
@@ -131,76 +124,106 @@ __device__ __forceinline__ float pc_log_add_t(const pc_tables* t, float x, float
   return d >= 7.5f ? hi : r;
 }
 
-// Two independent LOG_ADDs at once, (x.x (+) y.x, x.y (+) y.y), on the packed FP32 pipe: v_pk_mul_f32 /
-// v_pk_add_f32 do both lanes' multiply or add in one issue slot, and with contraction off they stay
-// separate roundings, i.e. the same operations as two calls of pc_log_add_t.
-typedef float pc_f2 __attribute__((ext_vector_type(2)));
-// Slot of the cubic for 2d in the coefficient rows: -ceil(2d) is one instruction (v_cvt_flr_i32_f32 of the negated
-// operand; floor(-x) = -ceil(x)), and its low four bits are a valid slot for every d: 0 for d = 0, 16 - ceil(2d)
-// for 0 < d < 7.5 (pc_tables_init2 lays the rows out that way), anything in 0..15 for the d >= 7.5 that the
-// caller's select throws away (LOG_ZERO operands give 4e20 and saturate the conversion).  Returns the byte offset.
-__device__ __forceinline__ unsigned pc_slot4(float d2) {
-  int k;
-  asm("v_cvt_flr_i32_f32_e64 %0, -%1" : "=v"(k) : "v"(d2));
-  return ((unsigned)k << 2) & 60u;
+// The form the DP sweeps use: N independent LOG_ADDs at once, o[n] = x[n] (+) y[n], on values SCALED BY 32.
+// What the measurements on MI355X say (profiles/r02_a_valu_rate.txt, tools/valu_rate.hip): at two or more wavefronts
+// per SIMD the sweeps are bound by instruction issue -- plain f32/int adds, multiplies, ANDs and moves cost ~1.1 ns of
+// their SIMD each, every other vector instruction (min/max, compares, selects, conversions, shifts, packed f32, f64)
+// ~1.9 ns, an LDS read of up to 16 bytes per lane ~6.9 ns when all four SIMDs of the CU issue them.  Hence:
+//  * the 32x domain: every log-probability the sweeps carry is 32 times the reference's value.  Multiplying by a
+//    power of two commutes with IEEE rounding (no value here comes near the subnormal or overflow range; LOG_ZERO
+//    becomes -6.4e21 and keeps absorbing), so every sum, difference, comparison and the cubic
+//    ((k3/1024 * D + k2/32) * D + k1) * D + 32 k0, D = 32 d, are the reference's values times 32, bit for bit;
+//    the posterior step divides by 32 again.  What it buys: 32 d = hi - lo needs no multiply, and
+//  * one ds_read_b128 per LOG_ADD: slot (-ceil(32 d)) & 0xF0 = 16 * ((-ceil(2d)) & 15) for d < 7.5
+//    (ceil(ceil(x)/16) = ceil(x/16)) is the byte offset of the cubic in lq, from one conversion
+//    (v_cvt_flr_i32_f32 of the negated operand: floor(-x) = -ceil(x)) and one AND; d >= 7.5 (LOG_ZERO operands give
+//    1e22, which saturates the conversion) lands on some valid slot and is thrown away by the select;
+//  * seven plain adds/multiplies for the cubic (contraction is off: separate roundings, as in the reference);
+//  * the N lookups are issued together, between scheduling barriers -- left alone, the compiler sinks every
+//    lookup next to its polynomial and waits N times.
+#define PC_SCALE 32.0f
+#define PC_LOG_ZERO_S (PC_LOG_ZERO * PC_SCALE)
+template <int N>
+__device__ __forceinline__ void pc_log_add_n(const pc_tables* t, const float (&x)[N], const float (&y)[N], float (&o)[N]) {
+  float lo[N], hi[N], d[N];
+  int k[N];
+  float4 q[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    lo[n] = fminf(x[n], y[n]);
+    hi[n] = fmaxf(x[n], y[n]);
+    d[n] = hi[n] - lo[n];
+    asm("v_cvt_flr_i32_f32_e64 %0, -%1" : "=v"(k[n]) : "v"(d[n]));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+#if defined(PAIR_EXP_NOLDS)  // tuning experiment: what the lookups cost
+    q[n] = make_float4(__int_as_float(k[n]), 0.1f, 0.5f, 0.7f);
+#else
+    q[n] = *(const float4*)((const char*)t->lq + (k[n] & 240));
+#endif
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+#if defined(PAIR_EXP_NOPOLY)  // tuning experiment: what the cubic costs
+    const float r = q[n].x + lo[n];
+#else
+    const float r = ((q[n].x * d[n] + q[n].y) * d[n] + q[n].z) * d[n] + q[n].w + lo[n];
+#endif
+    o[n] = d[n] >= 7.5f * PC_SCALE ? hi[n] : r;
+  }
 }
-__device__ __forceinline__ pc_f2 pc_log_add2_t(const pc_tables* t, pc_f2 x, pc_f2 y) {
-  pc_f2 lo, hi;
-  lo.x = fminf(x.x, y.x); lo.y = fminf(x.y, y.y);
-  hi.x = fmaxf(x.x, y.x); hi.y = fmaxf(x.y, y.y);
-  const pc_f2 d = hi - lo;
-  const pc_f2 d2 = d + d;
-  const unsigned ka = pc_slot4(d2.x), kb = pc_slot4(d2.y);
-  const char* b0 = (const char*)t->lk[0], *b1 = (const char*)t->lk[1], *b2 = (const char*)t->lk[2], *b3 = (const char*)t->lk[3];
-  const pc_f2 k3 = {*(const float*)(b0 + ka), *(const float*)(b0 + kb)}, k2 = {*(const float*)(b1 + ka), *(const float*)(b1 + kb)};
-  const pc_f2 k1 = {*(const float*)(b2 + ka), *(const float*)(b2 + kb)}, k0 = {*(const float*)(b3 + ka), *(const float*)(b3 + kb)};
-  const pc_f2 r = (((k3 * d + k2) * d + k1) * d + k0) + lo;
-  pc_f2 o;
-  o.x = d.x >= 7.5f ? hi.x : r.x;
-  o.y = d.y >= 7.5f ? hi.y : r.y;
-  return o;
-}
-// LOG_ADD with one 16-byte lookup and plain (unpacked) float arithmetic.  Measured on MI355X
-// (profiles/r02_*_valu_rate.txt): with four or more wavefronts per SIMD v_add_f32 / v_mul_f32 issue at 2.5x the rate of
-// every other vector instruction, packed f32 included, and an LDS read costs its SIMD as much as 4-7 vector
-// instructions whatever its width -- so: one ds_read_b128 instead of four ds_read_b32, seven plain adds/multiplies,
-// and as few other instructions as the reference's semantics allow.
-// Slot: (-ceil(32 d)) & 0xF0 = 16 * ((-ceil(2d)) & 15) for d < 7.5 (ceil(ceil(x)/16) = ceil(x/16)), i.e. the byte offset
-// of the cubic in lq, from one conversion and one AND; d >= 7.5 lands on some valid slot and is thrown away.
-__device__ __forceinline__ float pc_log_add_q(const pc_tables* t, float x, float y) {
-  const float lo = fminf(x, y);
-  const float hi = fmaxf(x, y);
-  const float d = hi - lo;
-  const float d32 = d * 32.0f;
-  int k;
-  asm("v_cvt_flr_i32_f32_e64 %0, -%1" : "=v"(k) : "v"(d32));
-  const float4 q = *(const float4*)((const char*)t->lq + (k & 240));
-  const float r = ((q.x * d + q.y) * d + q.z) * d + q.w + lo;
-  return d >= 7.5f ? hi : r;
+__device__ __forceinline__ float pc_log_add_s(const pc_tables* t, float x, float y) {  // one LOG_ADD in the 32x domain
+  const float xs[1] = {x}, ys[1] = {y};
+  float o[1];
+  pc_log_add_n<1>(t, xs, ys, o);
+  return o[0];
 }
 
-template <bool LUT>
-__device__ __forceinline__ pc_f2 pc_log_add2(const pc_tables* t, pc_f2 x, pc_f2 y) {
-  if (LUT) return pc_log_add2_t(t, x, y);
-  pc_f2 o;
-  o.x = pc_log_add_t<false>(t, x.x, y.x);
-  o.y = pc_log_add_t<false>(t, x.y, y.y);
-  return o;
+// EXP (ScoreType.h:37-57) for x <= 0, N values of an array at once (the table reads issued together).  Piece boundaries are
+// -1/2, -1, -2, -4, -8, -16, i.e. the binary exponent of |x| selects the piece; index 6 holds zeros (x <= -16
+// returns 0).  The quartic is evaluated in double and narrowed, like the reference.
+template <int N, int OFF = 0, int TOT = N>
+__device__ __forceinline__ void pc_exp_chunk(const pc_tables* t, const float (&xf)[TOT], float (&o)[TOT]) {
+  int piece[N];
+  double2 h[N], m[N];
+  double c[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    const float a = fmaxf(-xf[OFF + n], 1.0e-30f);  // |x|, away from 0 so that the exponent is defined
+    int e;
+    (void)frexpf(a, &e);                            // a = m * 2^e, m in [0.5, 1)
+    // x > -0.5 <=> a < 0.5 <=> e <= -1 ; -1 < x <= -0.5 <=> e == 0 ; ... ; -16 < x <= -8 <=> e == 4
+    // (piece boundaries are closed on the lower side: x <= -0.5 leaves piece 0, matching a >= 0.5 <=> e >= 0)
+    piece[n] = min(max(e + 1, 0), 6);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int n = 0; n < N; ++n) { h[n] = t->exp_hi[piece[n]]; m[n] = t->exp_mid[piece[n]]; c[n] = t->exp_lo[piece[n]]; }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    const double x = (double)xf[OFF + n];
+    o[OFF + n] = (float)((((h[n].x * x + h[n].y) * x + m[n].x) * x + m[n].y) * x + c[n]);
+  }
 }
-
-// EXP (ScoreType.h:37-57) for x <= 0.  Piece boundaries are -1/2, -1, -2, -4, -8, -16, i.e. the
-// binary exponent of |x| selects the piece; index 6 holds zeros (x <= -16 returns 0).
-__device__ __forceinline__ float pc_exp_t(const pc_tables* t, float xf) {
-  const float a = fmaxf(-xf, 1.0e-30f);                   // |x|, away from 0 so that the exponent is defined
-  int e;
-  (void)frexpf(a, &e);                                     // a = m * 2^e, m in [0.5, 1)
-  // x > -0.5 <=> a < 0.5 <=> e <= -1 ; -1 < x <= -0.5 <=> e == 0 ; ... ; -16 < x <= -8 <=> e == 4
-  // (piece boundaries are closed on the lower side: x <= -0.5 leaves piece 0, matching a >= 0.5 <=> e >= 0)
-  const int piece = min(max(e + 1, 0), 6);
-  const double2 h = t->exp_hi[piece], m = t->exp_mid[piece];
-  const double c = t->exp_lo[piece];
-  const double x = (double)xf;
-  return (float)((((h.x * x + h.y) * x + m.x) * x + m.y) * x + c);
+// N values, three at a time (a chunk holds ten registers of coefficients per value)
+template <int N>
+__device__ __forceinline__ void pc_exp_n(const pc_tables* t, const float (&xf)[N], float (&o)[N]) {
+  if constexpr (N >= 1) pc_exp_chunk<(N >= 3 ? 3 : N), 0, N>(t, xf, o);
+  if constexpr (N >= 4) pc_exp_chunk<(N >= 6 ? 3 : N - 3), 3, N>(t, xf, o);
+  if constexpr (N >= 7) pc_exp_chunk<(N >= 9 ? 3 : N - 6), 6, N>(t, xf, o);
+  if constexpr (N >= 10) pc_exp_chunk<(N >= 12 ? 3 : N - 9), 9, N>(t, xf, o);
+  if constexpr (N >= 13) pc_exp_chunk<(N >= 15 ? 3 : N - 12), 12, N>(t, xf, o);
+  if constexpr (N >= 16) pc_exp_chunk<(N >= 18 ? 3 : N - 15), 15, N>(t, xf, o);
+  if constexpr (N >= 19) pc_exp_chunk<(N >= 21 ? 3 : N - 18), 18, N>(t, xf, o);
+  if constexpr (N >= 22) pc_exp_chunk<(N >= 24 ? 3 : N - 21), 21, N>(t, xf, o);
+  if constexpr (N >= 25) pc_exp_chunk<(N >= 27 ? 3 : N - 24), 24, N>(t, xf, o);
+  if constexpr (N >= 28) pc_exp_chunk<(N >= 30 ? 3 : N - 27), 27, N>(t, xf, o);
+  if constexpr (N >= 31) pc_exp_chunk<(N >= 33 ? 3 : N - 30), 30, N>(t, xf, o);
+  static_assert(N <= 33, "pc_exp_n: widen the chunk list");
 }
 
 }  // namespace dafs

@@ -64,7 +64,7 @@ def test_plan_covers_lengths():
         assert capi.pairhmm_plan(ntasks, l1, l2, p) == 0
         assert p.group in (16, 32, 64) and p.group * p.width >= l2 + 1
         assert p.slab_steps == l1 + p.group and p.nwaves % 4 == 0 and p.nwaves <= 8 * 1024
-        assert p.scratch_bytes == p.nwaves * p.slab_steps * p.width * 64 * 4
+        assert p.scratch_bytes == p.nwaves * p.slab_steps * p.width * 64 * 4 * 2  # DP slab + entry lists
     assert capi.pairhmm_plan(1, 10, 5000, p) == -4
     assert capi.pairhmm_plan(0, 10, 10, p) == -1
 

@@ -14,7 +14,7 @@
 #include <algorithm>
 
 #define REP 64     // instructions per kind per loop body (8 chains x 8)
-#define ITERS 2000
+#define ITERS 4000
 
 enum { K_ADD, K_MUL, K_MIN, K_CNDMASK, K_PKADD, K_PKMUL, K_ADD64, K_MUL64, K_FMA64, K_CVTFLR, K_LSHL, K_DPP, K_LDS32, K_LDS64, K_LDS128, K_MIX,
        K_FMA, K_MAX, K_AND, K_CND64, K_CMP, K_ADDU, K_LSHLADD, K_MOV, K_MED3, K_CVT64, K_ADDMIN, K_ADDLDS128, K_N };
@@ -109,15 +109,23 @@ static void run(int waves_per_simd, unsigned long long* d_cyc, float* d_sink, in
   // one 256-thread workgroup = one wavefront per SIMD of a CU; waves_per_simd workgroups per CU
   const int blocks = cus * waves_per_simd;
   hipLaunchKernelGGL(k_rate<K>, dim3(blocks), dim3(256), 0, 0, d_cyc, d_sink, 10);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0, 0);
   hipLaunchKernelGGL(k_rate<K>, dim3(blocks), dim3(256), 0, 0, d_cyc, d_sink, ITERS);
+  hipEventRecord(e1, 0);
   hipDeviceSynchronize();
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
   std::vector<unsigned long long> h(blocks * 4);
   hipMemcpy(h.data(), d_cyc, h.size() * sizeof h[0], hipMemcpyDeviceToHost);
   std::sort(h.begin(), h.end());
   const double med = (double)h[h.size() / 2];
   const double per_wave_instr = (K == K_MIX || K == K_ADDLDS128) ? (double)REP * 1.25 : (K == K_ADDMIN ? (double)REP * 2 : (double)REP);
   // cycles the SIMD spends per wave-instruction = wave time / (instructions per wave * waves sharing the SIMD)
-  printf(" | %dw %5.2f (%5.2f)", waves_per_simd, med / (per_wave_instr * ITERS * waves_per_simd), med / (per_wave_instr * ITERS));
+  // wall clock: ns the SIMD spends per wave-instruction (launch overhead included: ITERS is large)
+  printf(" | %dw %5.2f (%5.2f) %5.2fns", waves_per_simd, med / (per_wave_instr * ITERS * waves_per_simd), med / (per_wave_instr * ITERS),
+         ms * 1e6 / (per_wave_instr * ITERS * waves_per_simd));
 }
 
 template <int K>
