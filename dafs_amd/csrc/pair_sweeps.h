@@ -343,8 +343,8 @@ inline int pair_choose(pair_variant* vs, int nv, uint32_t ntasks, uint32_t max_l
     if (cap_occ > 0 && occ > cap_occ) occ = cap_occ;
     const uint64_t waves = ((uint64_t)ntasks + (64 / v.G) - 1) / (64 / v.G);
     const double n = (double)waves / (4.0 * cus);  // wavefronts per SIMD over the whole batch
-    const double k = n < 1.0 ? 1.0 : (n < occ ? n : (double)occ);  // resident at once
-    const double eff = k < 1.5 ? 0.5 : (k < 2.5 ? 0.75 : 1.0);
+    const double kres = n < 1.0 ? 1.0 : (n < occ ? n : (double)occ);  // resident at once
+    const double eff = kres < 1.5 ? 0.5 : (kres < 2.5 ? 0.75 : 1.0);
     const double step = (step_cost + cell_cost * (v.W - 0.5)) * (v.G == 64 ? 0.83 : 1.0);
     const double rounds = n > occ ? n / occ : 1.0;
     const double cost = (double)(max_len1 + v.G) * step * (n < 1.0 ? 1.0 : n) / eff * (1.0 - 0.17 * (1.0 - 1.0 / rounds));
