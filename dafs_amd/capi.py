@@ -123,6 +123,7 @@ _nodes_open = _sig("dafs_hip_nodes_open", C.c_int, [C.c_void_p, C.c_uint32, C.PO
 _nodes_advance = _sig("dafs_hip_nodes_advance", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(DDParams), C.c_uint32, C.c_void_p])
 _nodes_result = _sig("dafs_hip_nodes_result", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(NodeOutput)])
 _nodes_close = _sig("dafs_hip_nodes_close", C.c_int, [C.c_void_p])
+_nodes_memory = _sig("dafs_hip_nodes_memory", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
 _consensus_structure = _sig("dafs_hip_consensus_structure", C.c_int,
                             [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                              C.POINTER(C.c_float), C.c_void_p])
@@ -371,6 +372,12 @@ class Context:
 
     def nodes_close(self):
         check(_nodes_close(self._h))
+
+    def nodes_memory(self):
+        """(reserved, in_use, peak) bytes of the resident nodes' device memory"""
+        r, u, p = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(_nodes_memory(self._h, C.byref(r), C.byref(u), C.byref(p)))
+        return r.value, u.value, p.value
 
     def consensus_structure(self, seq, mask, th, want_p=False):
         seq = np.ascontiguousarray(seq, np.uint32); mask = np.ascontiguousarray(mask, np.uint8)

@@ -179,16 +179,26 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
   for (uint32_t b = 0; b < nnodes; ++b) {
     const dafs_node_input& ni = in[b];
     if (!ni.n1 || !ni.n2 || !ni.len1 || !ni.len2 || !ni.seq1 || !ni.seq2 || !ni.mask1 || !ni.mask2) return DAFS_HIP_EINVAL;
-    if (ni.len1 > DD_LMAX || ni.len2 > DD_LMAX - 1) return DAFS_HIP_ETOOLONG;  // wave DPs: 64 lanes x 64 columns
     int rc;
     if ((rc = make_geom(c, ni.n1, ni.len1, ni.seq1, ni.mask1, g1[b]))) return rc;
     if ((rc = make_geom(c, ni.n2, ni.len2, ni.seq2, ni.mask2, g2[b]))) return rc;
   }
 
+  // DAFS_HIP_DD_WIDE=1 (tests): every node takes the forms of alignments too wide for the on-chip placements -- foldings
+  // span-ordered on HBM tables without sweep-order copies, the alignment wave DP without input row buffers, row
+  // pointers searched in HBM, one averaging row per workgroup
+  const char* wide_env = getenv("DAFS_HIP_DD_WIDE");
+  const bool force_wide = wide_env && atoi(wide_env) != 0;
   // ---- carve each node's block (two passes: size, then pointers) ----
   std::vector<dd_node> nodes(nnodes);
   std::vector<std::vector<uint8_t>> heads(nnodes);  // upload staging, alive until the first synchronisation below
   std::vector<size_t> lds(nnodes, 0), split_lds(nnodes, 0);
+  std::vector<uint8_t*> blk0(nnodes, nullptr), blk1(nnodes, nullptr);
+  std::vector<size_t> blk0_bytes(nnodes, 0), blk1_bytes(nnodes, 0);
+  auto undo = [&](int rc) {  // a failed open gives its blocks back
+    for (uint32_t b = 0; b < nnodes; ++b) { c->dd_free(blk0[b], blk0_bytes[b]); c->dd_free(blk1[b], blk1_bytes[b]); }
+    return rc;
+  };
   for (uint32_t b = 0; b < nnodes; ++b) {
     const dafs_node_input& ni = in[b];
     dd_node& nd = nodes[b];
@@ -221,12 +231,17 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
       carve_nuss(cv, L2, nd.wy);
       nd.dp_z = cv.take<float>(T); nd.tr_z = cv.take<uint8_t>(T);
       nd.trb_x = cv.take<uint8_t>(XX / 2 + L1 + 16); nd.trb_y = cv.take<uint8_t>(YY / 2 + L2 + 16);
-      nd.s_x = cv.take<float>(((size_t)L1 + 63) * dd_fold_cols(L1) * 64); nd.s_y = cv.take<float>(((size_t)L2 + 63) * dd_fold_cols(L2) * 64);  // steps x columns per lane x 64 lanes
+      // steps x columns per lane x 64 lanes; only for foldings that have a register form
+      nd.s_x = (dd_fold_cols(L1) <= DD_WFOLD && !force_wide) ? cv.take<float>(((size_t)L1 + 63) * dd_fold_cols(L1) * 64) : nullptr;
+      nd.s_y = (dd_fold_cols(L2) <= DD_WFOLD && !force_wide) ? cv.take<float>(((size_t)L2 + 63) * dd_fold_cols(L2) * 64) : nullptr;
       nd.pz_s = cv.take<float>(((size_t)L1 + 63) * ((L2 + 64) / 64) * 64); nd.qz_s = cv.take<float>(((size_t)L1 + 63) * ((L2 + 64) / 64) * 64);
       nd.trk_x = nd.wx.tr; nd.trk_y = nd.wy.tr;  // the L*L uint32 tables double as bifurcation codes
       {  // LDS plan (mirrors the carving at the top of k_dd_solve / dd_folder)
-        const size_t base_z = (size_t)3 * ((L2 + 64) / 64) * 64 * 4;                       // row buffers of the alignment DP
-        const size_t slow_x = (size_t)dd_slow_words(L1) * 4, slow_y = (size_t)dd_slow_words(L2) * 4;  // HBM-table folding forms
+        // row buffers of the alignment DP: the previous row and, while they fit, the two input rows (nw_wave)
+        size_t base_z = (size_t)3 * ((L2 + 64) / 64) * 64 * 4;
+        uint32_t lean = 0;
+        if (base_z > kDdLdsBudget - 4096 || force_wide) { base_z /= 3; lean = 32u; }
+        if (base_z > kDdLdsBudget - 4096) return undo(DAFS_HIP_ETOOLONG);  // second alignment beyond ~38 000 columns
         auto nib = [](uint32_t L) { return ((size_t)L * (L + 1) / 2 + 7) / 8; };           // packed traceback codes, words
         // a fast folding DP: codes, the rows in flight (one per active lane), DD_CAP split rows per column
         auto fast = [&](uint32_t L) { return (nib(L) + dd_ring_words(L) + (size_t)DD_CAP * L) * 4; };
@@ -237,25 +252,26 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
         auto fast_g = [&](uint32_t L) { return ((size_t)dd_ring_words(L) + (size_t)DD_CAP * L) * 4; };  // traceback codes in HBM
         auto wide_ok = [](uint32_t L, uint32_t cols) { return dd_fold_cols(L) <= cols; };  // a register form exists for this width
         size_t used = base_z;
-        nd.lds_flags = 0;
-        if (used + fast(L1) + fast(L2) <= kDdLdsBudget) { used += fast(L1) + fast(L2); nd.lds_flags = 2u | 4u; }  // x and y side by side
-        else if (wide_ok(L1, DD_WREG) && wide_ok(L2, DD_WREG) && used + shared <= kDdLdsBudget) { used += shared; nd.lds_flags = 8u; }      // one region, x then y
-        else if (wide_ok(L1, DD_WFOLD) && wide_ok(L2, DD_WFOLD) && used + shared_g <= kDdLdsBudget) { used += shared_g; nd.lds_flags = 8u | 16u; }  // the same, codes in HBM
-        else used += slow_x + slow_y;
-        if (used + need_z <= kDdLdsBudget) { used += need_z; nd.lds_flags |= 1u; }
+        nd.lds_flags = lean;
+        if (force_wide) {}
+        else if (used + fast(L1) + fast(L2) <= kDdLdsBudget) { used += fast(L1) + fast(L2); nd.lds_flags |= 2u | 4u; }  // x and y side by side
+        else if (wide_ok(L1, DD_WREG) && wide_ok(L2, DD_WREG) && used + shared <= kDdLdsBudget) { used += shared; nd.lds_flags |= 8u; }      // one region, x then y
+        else if (wide_ok(L1, DD_WFOLD) && wide_ok(L2, DD_WFOLD) && used + shared_g <= kDdLdsBudget) { used += shared_g; nd.lds_flags |= 8u | 16u; }  // the same, codes in HBM
+        // else: foldings without a register form run span-ordered on HBM tables and need no LDS
+        if (used + need_z <= kDdLdsBudget && !force_wide) { used += need_z; nd.lds_flags |= 1u; }
         lds[b] = used;
         // split plan: each folding DP on a workgroup of its own.  Worth it when the two do not run side by side
         // in one workgroup; the leader then keeps only the alignment DP (its LDS need is covered by `used`).
         nd.split = 0; nd.fold_fast = 0;
         split_lds[b] = 0;
-        if (!(nd.lds_flags & 2)) {
+        if (!(nd.lds_flags & 2) && !force_wide) {
           size_t worst = 0;
           const uint32_t Ls[2] = {L1, L2};
           for (int r = 0; r < 2; ++r) {
             const uint32_t L = Ls[r];
             if (wide_ok(L, DD_WREG) && fast(L) <= kDdLdsBudget) { nd.fold_fast |= 1u << r; worst = std::max(worst, fast(L)); }
             else if (wide_ok(L, DD_WFOLD) && fast_g(L) <= kDdLdsBudget) { nd.fold_fast |= 4u << r; worst = std::max(worst, fast_g(L)); }
-            else worst = std::max(worst, (size_t)dd_slow_words(L) * 4);
+            // else span-ordered on HBM tables: no LDS
           }
           // also worth it when a folding has no register form at all: its folder runs the span-ordered form on a
           // whole workgroup, far ahead of the HBM-table wave form the leader would run for it
@@ -273,7 +289,8 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
       nd.score = cv.take<float>(1); nd.info = cv.take<uint32_t>(16); nd.fstate = cv.take<float>(4);
       if (pass == 0) {
         cv.base = c->dd_alloc(cv.used + 256);
-        if (!cv.base) return DAFS_HIP_ENOMEM;
+        if (!cv.base) return undo(DAFS_HIP_ENOMEM);
+        blk0[b] = cv.base; blk0_bytes[b] = cv.used + 256;
       }
     }
     for (const region& r : fills)
@@ -299,9 +316,9 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
   const bp_store_dev bpv = bps.view();
   uint32_t max_len = 0;
   for (uint32_t b = 0; b < nnodes; ++b) max_len = std::max(max_len, std::max(in[b].len1, in[b].len2));
-  if ((rc = dd_avg_launch(c->d_nodes.ptr, nnodes, max_len, mpv, bpv, c->stream))) return rc;
+  if ((rc = dd_avg_launch(c->d_nodes.ptr, nnodes, max_len, mpv, bpv, force_wide ? 1 : 0, c->stream))) return rc;
   if ((rc = c->d_paused.reserve(nnodes))) return rc;  // doubles as the landing place of the per-node counts
-  if ((rc = dd_lists_launch(c->d_nodes.ptr, nnodes, dp, c->d_paused.ptr, c->stream))) return rc;
+  if ((rc = dd_lists_launch(c->d_nodes.ptr, nnodes, force_wide ? 0 : max_len, dp, c->d_paused.ptr, c->stream))) return rc;
   // ---- consensus base-pair counts -> each node's second block ----
   std::vector<uint32_t> counts(nnodes);
   if (hip_check(hipMemcpyAsync(counts.data(), c->d_paused.ptr, (size_t)nnodes * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
@@ -316,13 +333,14 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
       nodes[b].sw = cb.take<float>((size_t)ncbp + 1);
       if (pass == 0) {
         cb.base = c->dd_alloc(cb.used + 256);
-        if (!cb.base) return DAFS_HIP_ENOMEM;
+        if (!cb.base) return undo(DAFS_HIP_ENOMEM);
+        blk1[b] = cb.base; blk1_bytes[b] = cb.used + 256;
       }
     }
   }
   if ((rc = c->d_nodes.upload(nodes.data(), nnodes, c->stream))) return rc;
-  if ((rc = dd_cbp_fill_launch(c->d_nodes.ptr, nnodes, dp, c->stream))) return rc;
-  for (uint32_t b = 0; b < nnodes; ++b) c->dd_open.push_back({nodes[b], lds[b], split_lds[b], false});
+  if ((rc = dd_cbp_fill_launch(c->d_nodes.ptr, nnodes, force_wide ? 0 : max_len, dp, c->stream))) return rc;
+  for (uint32_t b = 0; b < nnodes; ++b) c->dd_open.push_back({nodes[b], lds[b], split_lds[b], false, {blk0[b], blk1[b]}, {blk0_bytes[b], blk1_bytes[b]}, false});
   return DAFS_HIP_OK;
 }
 
@@ -352,7 +370,7 @@ int nodes_advance(dafs_hip_ctx* c, uint32_t n, const uint32_t* handles, dd_param
     const dafs_hip_ctx::dd_open_node& on = c->dd_open[handles[who[b]]];
     if (split && on.split_lds) {
       nodes[b].split = 1;
-      nodes[b].lds_flags &= 1u;  // the leader keeps the alignment DP only
+      nodes[b].lds_flags &= (1u | 32u);  // the leader keeps the alignment DP only
       lds_max = std::max(lds_max, on.split_lds);
       if (hip_check(hipMemsetAsync(nodes[b].sync, 0, 4, c->stream))) return DAFS_HIP_ELAUNCH;  // clear the exit mark of the last launch
     } else {
@@ -377,7 +395,7 @@ int nodes_advance(dafs_hip_ctx* c, uint32_t n, const uint32_t* handles, dd_param
 }
 
 int nodes_result(dafs_hip_ctx* c, uint32_t handle, dafs_node_output* out, bool stamps) {
-  if (handle >= c->dd_open.size() || !c->dd_open[handle].finished) return DAFS_HIP_EINVAL;
+  if (handle >= c->dd_open.size() || !c->dd_open[handle].finished || c->dd_open[handle].released) return DAFS_HIP_EINVAL;
   const dd_node& nd = c->dd_open[handle].nd;
   uint32_t info[16];
   float score = 0.0f;
@@ -402,6 +420,11 @@ int nodes_result(dafs_hip_ctx* c, uint32_t handle, dafs_node_output* out, bool s
   out->ncbp = info[0];
   out->iterations = info[1];
   out->violated = info[2];
+  {  // the node's device memory is free for the nodes opened from now on (work on one stream: ordered behind this copy)
+    dafs_hip_ctx::dd_open_node& on = c->dd_open[handle];
+    for (int k = 0; k < 2; ++k) c->dd_free(on.blk[k], on.blk_bytes[k]);
+    on.released = true;
+  }
   return info[3] ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;  // info[3]: the alignment traceback left the envelope
 }
 
@@ -441,6 +464,16 @@ extern "C" int dafs_hip_nodes_close(dafs_hip_ctx* c) {
   if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
   if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
   c->dd_reset();
+  return DAFS_HIP_OK;
+}
+
+extern "C" int dafs_hip_nodes_memory(dafs_hip_ctx* c, uint64_t* reserved, uint64_t* in_use, uint64_t* peak) {
+  if (!c) return DAFS_HIP_EINVAL;
+  uint64_t r = 0;
+  for (const dafs_hip_ctx::dd_chunk& ch : c->dd_chunks) r += ch.cap;
+  if (reserved) *reserved = r;
+  if (in_use) *in_use = c->dd_in_use;
+  if (peak) *peak = c->dd_peak;
   return DAFS_HIP_OK;
 }
 
@@ -503,7 +536,7 @@ extern "C" int dafs_hip_consensus_structure(dafs_hip_ctx* c, uint32_t n, uint32_
   if ((rc = c->d_nodes.upload(&nd, 1, c->stream))) return rc;
   mp_store_dev none;
   memset(&none, 0, sizeof none);
-  if ((rc = dd_avg_launch(c->d_nodes.ptr, 1, len, none, bps.view(), c->stream))) return rc;
+  if ((rc = dd_avg_launch(c->d_nodes.ptr, 1, len, none, bps.view(), 0, c->stream))) return rc;
   if ((rc = nussinov_launch(len, nd.p_x, nullptr, 0.0f, th, nd.wx, d_ss, nd.score, c->stream))) return rc;
   float s = 0;
   if (hip_check(hipMemcpyAsync(ss, d_ss, (size_t)len * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <iterator>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -123,25 +125,72 @@ struct dafs_hip_ctx {
   dafs::dev_buf<uint8_t> work, work2;
   dafs::dev_buf<dafs::dd_node> d_nodes;
   dafs::dev_buf<uint32_t> d_paused;  // per node of a launch: still unfinished
-  // resident tree nodes (dafs_hip_nodes_open / _advance / _result / _close): device memory that lives until
-  // _close, in large chunks that are kept for the next phase
-  struct dd_chunk { uint8_t* ptr; size_t cap, used; };
+  // resident tree nodes (dafs_hip_nodes_open / _advance / _result / _close).  Their device memory comes from large
+  // chunks that are kept for the next phase; a node's blocks go back to an address-ordered free list (neighbours
+  // merged) as soon as its result has been copied out (dafs_hip_nodes_result), so a progressive run holds the nodes
+  // that are open, not every node of the tree (a node is ~40 L^2 bytes: 3 GB at 8600 columns).
+  struct dd_chunk { uint8_t* ptr; size_t cap; };
   std::vector<dd_chunk> dd_chunks;
-  struct dd_open_node { dafs::dd_node nd; size_t lds, split_lds; bool finished; };
+  std::map<uint8_t*, size_t> dd_free_blocks;  // start -> bytes
+  size_t dd_in_use = 0, dd_peak = 0;
+  struct dd_open_node { dafs::dd_node nd; size_t lds, split_lds; bool finished; uint8_t* blk[2]; size_t blk_bytes[2]; bool released; };
   std::vector<dd_open_node> dd_open;
+  void dd_free(uint8_t* p, size_t bytes) {
+    if (!p || !bytes) return;
+    bytes = (bytes + 255) & ~(size_t)255;
+    dd_in_use -= bytes;
+    auto it = dd_free_blocks.emplace(p, bytes).first;
+    auto nx = std::next(it);
+    if (nx != dd_free_blocks.end() && it->first + it->second == nx->first && same_chunk(it->first, nx->first)) { it->second += nx->second; dd_free_blocks.erase(nx); }
+    if (it != dd_free_blocks.begin()) {
+      auto pv = std::prev(it);
+      if (pv->first + pv->second == it->first && same_chunk(pv->first, it->first)) { pv->second += it->second; dd_free_blocks.erase(it); }
+    }
+  }
+  bool same_chunk(const uint8_t* a, const uint8_t* b) const {
+    for (const dd_chunk& ch : dd_chunks)
+      if (a >= ch.ptr && a < ch.ptr + ch.cap) return b >= ch.ptr && b < ch.ptr + ch.cap;
+    return false;
+  }
   uint8_t* dd_alloc(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
-    for (dd_chunk& ch : dd_chunks)
-      if (ch.cap - ch.used >= bytes) { uint8_t* p = ch.ptr + ch.used; ch.used += bytes; return p; }
-    dd_chunk ch;
-    ch.cap = bytes > ((size_t)256 << 20) ? bytes : ((size_t)256 << 20);
-    ch.used = bytes;
-    if (dafs::hip_check(hipMalloc((void**)&ch.ptr, ch.cap))) return nullptr;
-    dd_chunks.push_back(ch);
-    return ch.ptr;
+    auto best = dd_free_blocks.end();
+    for (auto it = dd_free_blocks.begin(); it != dd_free_blocks.end(); ++it)
+      if (it->second >= bytes && (best == dd_free_blocks.end() || it->second < best->second)) best = it;
+    if (best == dd_free_blocks.end()) {
+      // nothing fits: chunks that are entirely free go back to the device first (a wide node may have left a chunk of
+      // several GB behind that no later node fills)
+      for (size_t k = 0; k < dd_chunks.size();) {
+        auto it = dd_free_blocks.find(dd_chunks[k].ptr);
+        if (it != dd_free_blocks.end() && it->second == dd_chunks[k].cap) {
+          dd_free_blocks.erase(it);
+          (void)hipFree(dd_chunks[k].ptr);
+          dd_chunks.erase(dd_chunks.begin() + (long)k);
+        } else {
+          ++k;
+        }
+      }
+      dd_chunk ch;
+      ch.cap = bytes > ((size_t)256 << 20) ? bytes : ((size_t)256 << 20);
+      if (dafs::hip_check(hipMalloc((void**)&ch.ptr, ch.cap))) return nullptr;
+      dd_chunks.push_back(ch);
+      best = dd_free_blocks.emplace(ch.ptr, ch.cap).first;
+    }
+    uint8_t* p = best->first;
+    const size_t rest = best->second - bytes;
+    dd_free_blocks.erase(best);
+    if (rest) dd_free_blocks.emplace(p + bytes, rest);
+    dd_in_use += bytes;
+    if (dd_in_use > dd_peak) dd_peak = dd_in_use;
+    return p;
   }
-  void dd_reset() { for (dd_chunk& ch : dd_chunks) ch.used = 0; dd_open.clear(); }
-  void dd_release() { for (dd_chunk& ch : dd_chunks) (void)hipFree(ch.ptr); dd_chunks.clear(); dd_open.clear(); }
+  void dd_reset() {
+    dd_free_blocks.clear();
+    for (dd_chunk& ch : dd_chunks) dd_free_blocks.emplace(ch.ptr, ch.cap);
+    dd_in_use = 0;
+    dd_open.clear();
+  }
+  void dd_release() { for (dd_chunk& ch : dd_chunks) (void)hipFree(ch.ptr); dd_chunks.clear(); dd_free_blocks.clear(); dd_in_use = 0; dd_open.clear(); }
   uint32_t max_len() const { uint32_t m = 0; for (uint32_t l : len) m = l > m ? l : m; return m; }
 
   void free_all() {

@@ -27,9 +27,11 @@ struct dd_node {
   uint8_t* tr_z;      // (L1+1)*(L2+1)   traceback codes of the alignment DP (HBM copy, used when it does not fit LDS)
   uint8_t *trb_x, *trb_y;   // L(L+1)/2 each: Nussinov traceback codes 0..4 (HBM copies)
   uint32_t *trk_x, *trk_y;  // L*L each: bifurcation code of the cells whose traceback code is 4
-  float *s_x, *s_y;         // (L+63)*ceil(L/64)*64 each: pair scores w*(p-th)-q in sweep order of the folding DP
+  float *s_x, *s_y;         // (L+63)*ceil(L/64)*64 each: pair scores w*(p-th)-q in sweep order of the folding DP; null when the
+                            // folding has no register form (more than DD_WFOLD columns per lane)
   float *pz_s, *qz_s;       // (L1+63)*ceil((L2+1)/64)*64 each: p_z, q_z in sweep order of the alignment DP
-  uint32_t lds_flags;       // LDS plan: bit 0 packed alignment traceback, bit 1 / bit 2 fast form of the x / y folding DP
+  uint32_t lds_flags;       // LDS plan: bit 0 packed alignment traceback, bit 1 / bit 2 fast form of the x / y folding DP, bit 3 / 4 shared region / codes in HBM,
+                            // bit 5 alignment wave DP without input row buffers (second alignment too long for them)
   uint32_t* env;      // 2*(L1+1)
   // sparse structure of p_x / p_y / p_z (> CUTOFF) and of the consensus base pairs
   int32_t *xmap, *ymap, *zmap;    // dense cell -> entry id (px / py / cz lists) or -1
@@ -63,10 +65,9 @@ struct dd_params {
                    // marked paused and continues from where it stopped at the next launch
 };
 
-int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_store_dev mp, bp_store_dev bp, hipStream_t st);
-int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, uint32_t* d_ncbp, hipStream_t st);  // d_ncbp[b]: consensus pairs of node b
-int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st);
-#define DD_LMAX 4096  // longest child alignment the node kernels take (64 lanes x 64 columns; LDS row buffers)
+int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_store_dev mp, bp_store_dev bp, int one_row, hipStream_t st);
+int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, dd_params prm, uint32_t* d_ncbp, hipStream_t st);  // d_ncbp[b]: consensus pairs of node b
+int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, dd_params prm, hipStream_t st);
 #define DD_WREG 8     // widest lane (columns) of the register-resident alignment DP, and of the folding DP with its codes in LDS
 #define DD_WFOLD 16   // widest lane of the register-resident folding DP (codes in HBM beyond DD_WREG)
 #define DD_CAP 4  // candidates per column kept in LDS by the fast folding DP

@@ -616,10 +616,13 @@ __device__ float nw_wave(uint32_t L1, uint32_t L2, const float* __restrict__ ps_
   DD_LDS float* Pb = (DD_LDS float*)Pb_;
   DD_LDS float* Qb = (DD_LDS float*)Qb_;
   const uint32_t W = (L2 + 1 + 63) / 64, T = L2 + 1;
+  const bool buf = Pb_ != nullptr;  // without room for the input row buffers (second alignments beyond ~12 000 columns) the cells read HBM
   for (uint32_t c = 0; c < W; ++c) {
     P[c * 64 + lane] = 0.0f;  // row 0
-    Pb[c * 64 + lane] = ps[(size_t)c * 64 + lane];
-    Qb[c * 64 + lane] = qs[(size_t)c * 64 + lane];
+    if (buf) {
+      Pb[c * 64 + lane] = ps[(size_t)c * 64 + lane];
+      Qb[c * 64 + lane] = qs[(size_t)c * 64 + lane];
+    }
   }
   float last = 0.0f, leftprev = 0.0f, score = 0.0f;
   const int nsteps = (int)L1 + (int)((L2 + W) / W) - 1;  // lanes beyond column L2 have nothing to do
@@ -629,7 +632,7 @@ __device__ float nw_wave(uint32_t L1, uint32_t L2, const float* __restrict__ ps_
     const int i = s - lane + 1;
     const bool rowv = i >= 1 && i <= (int)L1;
     float np[DD_WMAX], nq[DD_WMAX];
-    const bool nv = s + 1 < nsteps;
+    const bool nv = buf && s + 1 < nsteps;
 #pragma unroll
     for (int c = 0; c < DD_WMAX; ++c) {
       const bool on = nv && (uint32_t)c < W;
@@ -649,8 +652,9 @@ __device__ float nw_wave(uint32_t L1, uint32_t L2, const float* __restrict__ ps_
       if (rowv && k <= L2) {
         if (k == 0) v = 0.0f;
         else if (k >= ef && k <= es) {
-          v = diag + Pb[c * 64 + lane] - th;
-          v = v + Qb[c * 64 + lane];
+          const size_t o = ((size_t)s * W + c) * 64 + lane;
+          v = diag + (buf ? Pb[c * 64 + lane] : ps[o]) - th;
+          v = v + (buf ? Qb[c * 64 + lane] : qs[o]);
           uint8_t t = 'M';
           if (v < up) { v = up; t = 'X'; }
           if (v < left) { v = left; t = 'Y'; }
@@ -665,12 +669,14 @@ __device__ float nw_wave(uint32_t L1, uint32_t L2, const float* __restrict__ ps_
     leftprev = recv;
     last = v;
     ef = nef; es = nes;
+    if (buf) {
 #pragma unroll
-    for (int c = 0; c < DD_WMAX; ++c)
-      if ((uint32_t)c < W) { Pb[c * 64 + lane] = np[c]; Qb[c * 64 + lane] = nq[c]; }
-    for (uint32_t c = DD_WMAX; c < W; ++c) {
-      Pb[c * 64 + lane] = nv ? ps[((size_t)(s + 1) * W + c) * 64 + lane] : 0.0f;
-      Qb[c * 64 + lane] = nv ? qs[((size_t)(s + 1) * W + c) * 64 + lane] : 0.0f;
+      for (int c = 0; c < DD_WMAX; ++c)
+        if ((uint32_t)c < W) { Pb[c * 64 + lane] = np[c]; Qb[c * 64 + lane] = nq[c]; }
+      for (uint32_t c = DD_WMAX; c < W; ++c) {
+        Pb[c * 64 + lane] = nv ? ps[((size_t)(s + 1) * W + c) * 64 + lane] : 0.0f;
+        Qb[c * 64 + lane] = nv ? qs[((size_t)(s + 1) * W + c) * 64 + lane] : 0.0f;
+      }
     }
   }
   return __shfl(score, (int)(L2 / W));
@@ -766,12 +772,12 @@ __device__ void avg_row(uint32_t nsrc, float scale_div, GetSrc get, float* row, 
 }
 
 __global__ __launch_bounds__(256) void k_node_avg(const dd_node* nodes, mp_store_dev mp, bp_store_dev bp, uint32_t row_cap) {
-  extern __shared__ float s_rows[];  // 4 x row_cap: one accumulator row per wavefront
+  extern __shared__ float s_rows[];  // (blockDim.x / 64) x row_cap: one accumulator row per wavefront
   __shared__ uint2 s_stage[4][AVG_STAGE];
   const dd_node nd = nodes[blockIdx.y];
   const uint32_t role = blockIdx.z;
   const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-  const uint32_t I = blockIdx.x * 4 + wave;
+  const uint32_t I = blockIdx.x * (blockDim.x >> 6) + wave;
   float* row = s_rows + (size_t)wave * row_cap;
   uint2* stage = s_stage[wave];
   if (role < 2) {
@@ -928,7 +934,7 @@ __device__ __forceinline__ uint32_t row_of_entry(const uint32_t* ptr, uint32_t R
   return lo;
 }
 
-__global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes, dd_params prm, uint32_t* ncbp_out) {
+__global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes, dd_params prm, uint32_t* ncbp_out, uint32_t pxptr_lds) {
   const dd_node nd = nodes[blockIdx.x];
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const uint32_t L1 = nd.L1, L2 = nd.L2;
@@ -940,8 +946,13 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes,
   if (tid == 0) s_total = 0;
   __syncthreads();
   uint32_t mine = 0;
-  __shared__ uint32_t s_pxptr[DD_LMAX + 4];
-  for (uint32_t i = tid; i <= L1; i += nt) s_pxptr[i] = nd.px_ptr[i];
+  // row pointers of p_x for the entry -> row searches: in LDS when the launch gave this node's L1 + 1 words room
+  extern __shared__ uint32_t s_pxptr_dyn[];
+  const uint32_t* s_pxptr = nd.px_ptr;
+  if ((size_t)(L1 + 1) * 4 <= pxptr_lds) {
+    for (uint32_t i = tid; i <= L1; i += nt) s_pxptr_dyn[i] = nd.px_ptr[i];
+    s_pxptr = s_pxptr_dyn;
+  }
   __syncthreads();
   const uint32_t npx = s_pxptr[L1];
   for (uint32_t e = tid; e < npx; e += nt) {  // a thread per entry of p_x
@@ -972,7 +983,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes,
   if (tid == 0) { nd.info[0] = s_total; nd.info[1] = 0; nd.info[2] = 0; nd.info[3] = 0; nd.info[4] = 0; nd.info[5] = 0; nd.info[6] = 0; nd.info[7] = 0; }
 }
 
-__global__ __launch_bounds__(DD_THREADS) void k_node_cbp_fill(const dd_node* nodes, dd_params prm) {
+__global__ __launch_bounds__(DD_THREADS) void k_node_cbp_fill(const dd_node* nodes, dd_params prm, uint32_t pxptr_lds) {
   const dd_node nd = nodes[blockIdx.x];
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const uint32_t L1 = nd.L1, L2 = nd.L2;
@@ -980,8 +991,12 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_cbp_fill(const dd_node* nod
   // prefix of the per-entry counts (entries are already in (i,j) order); entry e starts at incl[e] - count[e],
   // i.e. at incl[e-1]
   block_scan_inclusive(nd.cbp_cnt, npx);
-  __shared__ uint32_t s_pxptr[DD_LMAX + 4];
-  for (uint32_t i = tid; i <= L1; i += nt) s_pxptr[i] = nd.px_ptr[i];
+  extern __shared__ uint32_t s_pxptr_dyn[];
+  const uint32_t* s_pxptr = nd.px_ptr;
+  if ((size_t)(L1 + 1) * 4 <= pxptr_lds) {
+    for (uint32_t i = tid; i <= L1; i += nt) s_pxptr_dyn[i] = nd.px_ptr[i];
+    s_pxptr = s_pxptr_dyn;
+  }
   __syncthreads();
   for (uint32_t e = tid; e < npx; e += nt) {  // a thread per entry of p_x
     {
@@ -1157,19 +1172,17 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
   // traceback tables fit (nd.lds_flags, decided by the host): bit 0 alignment, bit 1 x, bit 2 y
   extern __shared__ unsigned char s_dd[];
   const uint32_t Wx = dd_fold_cols(L1), Wy = dd_fold_cols(L2), Wz = (L2 + 64) / 64;
+  const bool nw_lean = (nd.lds_flags & 32u) != 0;  // no room for the input row buffers of nw_wave
   float* Pz = (float*)s_dd;
-  float* Pbz = Pz + Wz * 64;
-  float* Qbz = Pbz + Wz * 64;
+  float* Pbz = nw_lean ? nullptr : Pz + Wz * 64;
+  float* Qbz = nw_lean ? nullptr : Pbz + Wz * 64;
   // previous-row buffers and candidate counters of the HBM-table folding forms: room of their own only when the
   // fold has no on-chip region (otherwise they borrow its ring, see dd_ring_words) and this workgroup folds at all
   const bool fastx = (nd.lds_flags & (2u | 8u)) != 0, fasty = (nd.lds_flags & (4u | 8u)) != 0;
   float *Px = nullptr, *Py = nullptr;
   unsigned char* lds_tail;
   {
-    float* q = Qbz + Wz * 64;
-    if (!split && !fastx) { Px = q; q += dd_slow_words(L1); }
-    if (!split && !fasty) { Py = q; q += dd_slow_words(L2); }
-    lds_tail = (unsigned char*)q;
+    lds_tail = (unsigned char*)(Pz + (size_t)(nw_lean ? 1 : 3) * Wz * 64);  // a folding without register form needs no LDS
   }
   // bit 0: packed alignment traceback; bit 1 / bit 2: the fast form of the x / y folding DP
   // (in-flight rows, candidate lists and packed traceback codes)
@@ -1200,8 +1213,8 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
   if (!resume) {
     nw_init_tr(L1, L2, trz);
     // sweep-order inputs of the three DPs, built once; the multiplier updates below keep them current
-    dd_fill_scores(L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_x);
-    dd_fill_scores(L2, nd.p_y, nd.q_y, w_y, prm.th_s, nd.s_y);
+    if (nd.s_x) dd_fill_scores(L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_x);  // only foldings with a register form keep one
+    if (nd.s_y) dd_fill_scores(L2, nd.p_y, nd.q_y, w_y, prm.th_s, nd.s_y);
     dd_fill_nw(L1, L2, nd.p_z, nd.q_z, nd.pz_s, nd.qz_s);
   }
   __syncthreads();
@@ -1264,12 +1277,12 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     }
     if (wave == 2) {
       float sc;
-      if (Wz <= DD_WREG) sc = trzp ? nw_wave_fast<true>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, (uint8_t*)trzp, lane)
+      if (Wz <= DD_WREG && !nw_lean) sc = trzp ? nw_wave_fast<true>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, (uint8_t*)trzp, lane)
                                    : nw_wave_fast<false>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, trz, lane);
       else sc = nw_wave(L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, trz, Pz, Pbz, Qbz, lane);
       if (lane == 0) {
         s_score[2] = sc;
-        const bool ok = (trzp && Wz <= DD_WREG) ? nw_traceback_packed(L1, L2, trzp, nd.z) : nw_traceback(L1, L2, trz, nd.z);
+        const bool ok = (trzp && Wz <= DD_WREG && !nw_lean) ? nw_traceback_packed(L1, L2, trzp, nd.z) : nw_traceback(L1, L2, trz, nd.z);
         if (!ok) s_bad = 1;
       }
     }
@@ -1365,7 +1378,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
           const size_t o = (size_t)i * L1 + j;
           const float qn = nd.q_x[o] - eta * (tc - 1);
           nd.q_x[o] = qn;
-          if (j >= i + 3) nd.s_x[nuss_skew(L1, Wx, i, j)] = w_x * (nd.p_x[o] - prm.th_s) - qn;
+          if (nd.s_x && j >= i + 3) nd.s_x[nuss_skew(L1, Wx, i, j)] = w_x * (nd.p_x[o] - prm.th_s) - qn;
         }
       }
       for (uint32_t e = nd.px_ptr[i]; e < nd.px_ptr[i + 1]; ++e) {
@@ -1377,7 +1390,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
           const size_t o = (size_t)i * L1 + jj;
           const float qn = nd.q_x[o] - eta * tc;
           nd.q_x[o] = qn;
-          if (jj >= i + 3) nd.s_x[nuss_skew(L1, Wx, i, jj)] = w_x * (nd.p_x[o] - prm.th_s) - qn;  // shorter spans stay 0 (dd_fill_scores)
+          if (nd.s_x && jj >= i + 3) nd.s_x[nuss_skew(L1, Wx, i, jj)] = w_x * (nd.p_x[o] - prm.th_s) - qn;  // shorter spans stay 0 (dd_fill_scores)
         }
       }
       const uint32_t kz = nd.z[i];
@@ -1412,7 +1425,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
           const size_t o = (size_t)k * L2 + l;
           const float qn = nd.q_y[o] - eta * (tc - 1);
           nd.q_y[o] = qn;
-          if (l >= k + 3) nd.s_y[nuss_skew(L2, Wy, k, l)] = w_y * (nd.p_y[o] - prm.th_s) - qn;
+          if (nd.s_y && l >= k + 3) nd.s_y[nuss_skew(L2, Wy, k, l)] = w_y * (nd.p_y[o] - prm.th_s) - qn;
         }
       }
       for (uint32_t e = nd.py_ptr[k]; e < nd.py_ptr[k + 1]; ++e) {
@@ -1424,7 +1437,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
           const size_t o = (size_t)k * L2 + ll;
           const float qn = nd.q_y[o] - eta * tc;
           nd.q_y[o] = qn;
-          if (ll >= k + 3) nd.s_y[nuss_skew(L2, Wy, k, ll)] = w_y * (nd.p_y[o] - prm.th_s) - qn;
+          if (nd.s_y && ll >= k + 3) nd.s_y[nuss_skew(L2, Wy, k, ll)] = w_y * (nd.p_y[o] - prm.th_s) - qn;
         }
       }
     }
@@ -1482,37 +1495,60 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_store_dev mp, bp_store_dev bp, hipStream_t st) {
-  if (!nnodes) return DAFS_HIP_OK;
-  if (max_len > DD_LMAX) return DAFS_HIP_ETOOLONG;
-  const uint32_t row_cap = (max_len + 63) & ~63u;
-  const size_t lds = (size_t)4 * row_cap * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hip_check(hipFuncSetAttribute((const void*)k_node_avg, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * DD_LMAX * 4))) return DAFS_HIP_ELAUNCH;
-    attr_set = true;
+// dynamic-LDS opt-in above 64 KB, once per device and kernel
+static int lds_optin(const void* fn, int slot, size_t bytes, size_t budget = kDdLdsBudget) {
+  static bool done[4][16] = {{false}};
+  int dev = 0;
+  if (hip_check(hipGetDevice(&dev))) return DAFS_HIP_ENODEV;
+  if (bytes <= 64 * 1024) return DAFS_HIP_OK;
+  if (dev < 0 || dev >= 16 || !done[slot][dev]) {
+    if (hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget))) return DAFS_HIP_ELAUNCH;
+    if (dev >= 0 && dev < 16) done[slot][dev] = true;
   }
-  hipLaunchKernelGGL(k_node_avg, dim3((max_len + 3) / 4, nnodes, 3), dim3(256), lds, st, d_nodes, mp, bp, row_cap);
+  return DAFS_HIP_OK;
+}
+
+int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_store_dev mp, bp_store_dev bp, int one_row, hipStream_t st) {
+  if (!nnodes) return DAFS_HIP_OK;
+  // one accumulator row per wavefront in LDS: four wavefronts per workgroup while four rows fit, then two, then one
+  const size_t budget = 124 * 1024;  // the kernel has 32 KB of static staging areas
+  const uint32_t row_cap = (max_len + 63) & ~63u;
+  uint32_t rows = one_row ? 1 : 4;
+  while (rows > 1 && (size_t)rows * row_cap * sizeof(float) > budget) rows >>= 1;
+  const size_t lds = (size_t)rows * row_cap * sizeof(float);
+  if (lds > budget) return DAFS_HIP_ETOOLONG;  // beyond ~31 000 columns
+  int rc = lds_optin((const void*)k_node_avg, 0, lds, budget);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_node_avg, dim3((max_len + rows - 1) / rows, nnodes, 3), dim3(64 * rows), lds, st, d_nodes, mp, bp, row_cap);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
-int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, uint32_t* d_ncbp, hipStream_t st) {
+int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, dd_params prm, uint32_t* d_ncbp, hipStream_t st) {
   if (!nnodes) return DAFS_HIP_OK;
-  hipLaunchKernelGGL(k_node_lists, dim3(nnodes), dim3(DD_THREADS), 0, st, d_nodes, prm, d_ncbp);
+  const size_t budget = 136 * 1024;  // 18 KB of static scan areas
+  size_t lds = max_len1 ? ((size_t)max_len1 + 4) * 4 : 0;  // 0: forced to the HBM search (tests)
+  if (lds > budget) lds = budget;  // longer row pointer arrays are searched in HBM
+  int rc = lds_optin((const void*)k_node_lists, 1, lds, budget);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_node_lists, dim3(nnodes), dim3(DD_THREADS), lds, st, d_nodes, prm, d_ncbp, (uint32_t)lds);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
-int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, hipStream_t st) {
+int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, dd_params prm, hipStream_t st) {
   if (!nnodes) return DAFS_HIP_OK;
-  hipLaunchKernelGGL(k_node_cbp_fill, dim3(nnodes), dim3(DD_THREADS), 0, st, d_nodes, prm);
+  const size_t budget = 150 * 1024;
+  size_t lds = max_len1 ? ((size_t)max_len1 + 4) * 4 : 0;
+  if (lds > budget) lds = budget;
+  int rc = lds_optin((const void*)k_node_cbp_fill, 2, lds, budget);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_node_cbp_fill, dim3(nnodes), dim3(DD_THREADS), lds, st, d_nodes, prm, (uint32_t)lds);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, bool split, uint32_t* d_paused, hipStream_t st) {
   if (!nnodes) return DAFS_HIP_OK;
-  static bool attr = false;
-  if (!attr) {
-    if (hip_check(hipFuncSetAttribute((const void*)k_dd_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDdLdsBudget))) return DAFS_HIP_ELAUNCH;
-    attr = true;
-  }
   if (lds_bytes > kDdLdsBudget) return DAFS_HIP_EINVAL;
+  {
+    const int rc = lds_optin((const void*)k_dd_solve, 3, lds_bytes);
+    if (rc) return rc;
+  }
   // split mode needs the three workgroups of a node on the machine together: the caller keeps 3 * nnodes within the CU count
   hipLaunchKernelGGL(k_dd_solve, dim3(nnodes, split ? 3 : 1), dim3(DD_SOLVE_THREADS), lds_bytes, st, d_nodes, prm, d_paused);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;

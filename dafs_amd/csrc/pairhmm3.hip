@@ -87,7 +87,6 @@ __device__ __forceinline__ void pairhmm3_pair(const dafs_pairhmm3_args& a, const
     int c1n = 6;  // row -t of step 0 is never an inner row
     for (int s = 0; s < nsteps; ++s) {
       const int i = s - t;
-      const bool rowv = (i >= 0) && (i <= L1);
       float* __restrict__ slab_s = slab + (size_t)s * (W * 64);
       const int c1 = c1n;
       c1n = (i >= 0 && i < L1) ? (int)s1[i] : 6;  // row i+1 of the next step

@@ -34,7 +34,6 @@ __device__ __forceinline__ void pairhmm5_pair(const dafs_pairhmm5_args& a, const
                                               float* __restrict__ slab, size_t plane, uint32_t* __restrict__ s_rowptr, int lane, int t, int g,
                                               int L1, int L2, int nsteps, bool act, uint32_t task,
                                               const uint8_t* __restrict__ s1, const uint8_t* __restrict__ s2) {
-  const contra_tables& s_ct = *ct;
   const float NI = CONTRA_NEG_INF;
   const float th = a.th;
   // transition scores into each state, by source state (InferenceEngine.ipp:139-226): read from the kernel

@@ -4,6 +4,8 @@ done by libdafs_hip.so on the GPU; this file only holds the guide tree, the alig
 (project_alignment) and the output format.  The C++ `dafs` executable (dafs_amd/csrc/cli_main.cpp)
 is the same logic for the drop-in command line."""
 import heapq
+import os
+import sys
 
 import numpy as np
 
@@ -131,6 +133,7 @@ def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25
     # consensus base pair to couple their subproblems need not run their two folding DPs (dafs_dd_params doc)
     prm = capi.dd_params(w=w, eta0=eta0, th_a=th_a, th_s=th_s, t_max=t_max, force_iters=force_iters,
                          skip_uncoupled_folds=1 if skip_uncoupled_folds else 0)
+    trace = os.environ.get("DAFS_PIPELINE_TRACE") == "1"  # node shapes on stderr as they are opened (diagnostics)
     res.dd_log = {}
     res.dd_dims = {}  # node -> (columns of the left, of the right alignment); resident-node mode only
     res.levels = 0
@@ -149,6 +152,8 @@ def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25
         while pending or open_nodes:
             ready = [i for i in pending if left[i] in aln and right[i] in aln]
             if ready:
+                if trace:
+                    print("open", [(i, aln[left[i]][1].shape, aln[right[i]][1].shape) for i in ready], file=sys.stderr, flush=True)
                 hs, dims = ctx.nodes_open([(aln[left[i]][0], aln[left[i]][1], aln[right[i]][0], aln[right[i]][1]) for i in ready], prm)
                 for i, h, d in zip(ready, hs, dims):
                     open_nodes[i] = (h, d[0], d[1])
@@ -165,6 +170,7 @@ def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25
                 res.dd_dims[i] = (l1, l2)
                 del aln[left[i]], aln[right[i]]
             res.levels += 1
+        res.dd_memory = ctx.nodes_memory()  # (reserved, in use, peak) bytes of the resident nodes
         ctx.nodes_close()
     root = 2 * n - 2
     sidx, mask = aln[root]

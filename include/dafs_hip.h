@@ -295,6 +295,9 @@ int dafs_hip_nodes_advance(dafs_hip_ctx* ctx, uint32_t n, const uint32_t* handle
                            uint8_t* finished);
 int dafs_hip_nodes_result(dafs_hip_ctx* ctx, uint32_t handle, dafs_node_output* out);
 int dafs_hip_nodes_close(dafs_hip_ctx* ctx);
+/* Device memory of the resident nodes (diagnostics): bytes reserved from the device, bytes held by open nodes now, and
+ * the largest value the latter has had.  A node's memory is returned when dafs_hip_nodes_result has copied it out. */
+int dafs_hip_nodes_memory(dafs_hip_ctx* ctx, uint64_t* reserved, uint64_t* in_use, uint64_t* peak);
 /* Final common structure of an alignment (src/dafs.cpp:1857-1871 without the RNAalifold term):
  * averaged base-pairing matrix -> SparseNussinov::decode(p,ss,str) with threshold th. */
 int dafs_hip_consensus_structure(dafs_hip_ctx* ctx, uint32_t n, uint32_t len, const uint32_t* seq, const uint8_t* mask,
