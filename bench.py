@@ -11,9 +11,10 @@ src/probconsRNA/ProbabilisticModel.h:105-403, src/dafs.cpp:155-167,713-764).
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
 
-With N > 1 the pairs of a sqrt(N)-times larger sequence set are dealt to the ranks by cost
-(weak scaling: ~8128 pairs per GPU), each rank runs its shard, and the sparse posteriors are
-exchanged with one all-gather over RCCL (the only collective of the path).
+With N > 1 the pairs of the SAME set (BASELINE.json's metric is N=128, L~150 at 1/2/4/8 GPUs: strong scaling) are dealt
+to the ranks by cost, each rank runs its shard, and the sparse posteriors are exchanged with one all-gather over RCCL
+(the only collective of the path).  --scaling weak grows the set by sqrt(N) instead (~8128 pairs per GPU);
+--config c2|c3|c4|c5 picks another BASELINE configuration (c4 = N=256, L~200, the multi-GPU config).
 
 Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
 "roofline" (algorithmic bytes / kernel time against the 8 TB/s HBM peak) and "cpu_baseline"
@@ -35,6 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 BASE_N, BASE_L = 128, 150
+CONFIGS = {"c2": (32, 80), "c3": (128, 150), "c4": (256, 200), "c5": (512, 400)}  # BASELINE.json configs (N, L)
 
 
 def build_shard(n_seq, length, world, rank, seed=12345):
@@ -47,35 +49,96 @@ def build_shard(n_seq, length, world, rank, seed=12345):
     return names, seqs, lens, px, py, total
 
 
-def cpu_baseline(seqs, px, py, th, budget_s=15.0):
-    """CPU path on a bounded sample of this rank's pairs, 1 thread.
-    kind "reference": the reference's own ProbCons::calculate (oracle/_ref, built from
-    /root/reference by oracle/Makefile) for the posterior + sparse rows, plus the oracle's
-    restatement of transpose_mp / calculate_similarity_score (dafs.cpp is not compilable here).
-    kind "port": the oracle restatement for everything."""
+def _pair_order(npairs, step=61):
+    # stride through the cost-sorted list so that any prefix of the sample spans all lengths
+    return [k for r in range(step) for k in range(r, npairs, step)]
+
+
+def _cpu_pairs_worker(job):
+    """one worker of the CPU baseline: its share of the sample, timed inside the worker"""
+    seqs, pairs, th, model, budget_s = job
     import oracle_lib
     orc = oracle_lib.load_oracle()
-    ref = oracle_lib.load_ref()
-    kind = "reference" if ref is not None else "port"
-    calc = ref.align_calculate if ref is not None else orc.align_calculate
+    ref = oracle_lib.load_ref() if model == 0 else None
+    calc = ref.align_calculate if ref is not None else (lambda a, b, t: orc.align_calculate(a, b, t, model))
     n = 0
     t0 = time.perf_counter()
-    step = 61  # stride through the cost-sorted list so any prefix of the sample spans all lengths
-    for k in [k for r in range(step) for k in range(r, len(px), step)]:
-        a, b = seqs[px[k]], seqs[py[k]]
+    for x, y in pairs:
+        a, b = seqs[x], seqs[y]
         rp, col, val = calc(a, b, th)
         orc.similarity(rp, col, val, len(a), len(b))
-        # transpose_mp
-        rows = np.repeat(np.arange(len(a), dtype=np.uint32), np.diff(rp))
+        rows = np.repeat(np.arange(len(a), dtype=np.uint32), np.diff(rp))  # transpose_mp
         o = np.lexsort((rows, col))
         _ = rows[o], val[o]
         n += 1
         if time.perf_counter() - t0 > budget_s:
             break
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "seq-pairs/s", "cores": 1, "kind": kind,
-            "sample": "%d of this rank's %d pairs (N=%d L~%d set), posterior+sparse rows+transpose+sim, %.1f s" %
-                      (n, len(px), len(seqs), BASE_L, dt)}
+    return n, time.perf_counter() - t0, ref is not None
+
+
+def cpu_baseline(seqs, px, py, th, model, length, budget_s=10.0):
+    """CPU path on a bounded sample of the pairs: one core (the reference has no threading), then process-parallel
+    over pairs on the host cores this job may use.
+    kind "reference": the reference's own ProbCons::calculate (oracle/_ref, built from /root/reference by
+    oracle/Makefile) for the posterior + sparse rows, plus the oracle's restatement of transpose_mp /
+    calculate_similarity_score (dafs.cpp is not compilable here).  kind "port": the oracle restatement for everything
+    (CONTRAlign runs, or boxes without oracle/_ref).  Must run before this process touches the GPU (it forks)."""
+    import multiprocessing as mp
+    order = _pair_order(len(px))
+    pairs = [(int(px[k]), int(py[k])) for k in order]
+    n1, dt1, is_ref = _cpu_pairs_worker((seqs, pairs, th, model, budget_s))
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    per = (len(pairs) + cores - 1) // cores
+    jobs = [(seqs, pairs[w::cores][:per], th, model, budget_s) for w in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_pairs_worker, jobs)
+    wall = time.perf_counter() - t0
+    n_all = sum(r[0] for r in res)
+    return {"value": n1 / dt1, "unit": "seq-pairs/s", "cores": 1, "kind": "reference" if is_ref else "port",
+            "sample": "%d of the %d pairs (N=%d L~%d set), posterior+sparse rows+transpose+sim, %.1f s" % (n1, len(px), len(seqs), length, dt1),
+            "all_cores": {"value": n_all / wall, "unit": "seq-pairs/s", "cores": cores,
+                          "sample": "%d pairs over %d worker processes, %.1f s wall" % (n_all, cores, wall)}}
+
+
+def cpu_end_to_end(names, seqs, model):
+    """the oracle's whole run (oracle/pipeline.c, one core) on the same set: wall-clock and phase split"""
+    import oracle_lib
+    orc = oracle_lib.load_oracle()
+    pl = orc.pipeline(names, seqs, orc.params(fold_model=0, align_model=model))
+    t0 = time.perf_counter()
+    pl.phase1()
+    t1 = time.perf_counter()
+    pl.phase2()
+    t2 = time.perf_counter()
+    out = pl.output()
+    sec = pl.seconds()
+    pl.close()
+    return {"wall_s": t2 - t0, "cores": 1, "kind": "port",
+            "phases_s": {"fold": round(sec[0], 3), "pair": round(sec[1], 3), "pct_tree": round(sec[2], 3), "progressive": round(sec[3], 3)},
+            "phase1_s": round(t1 - t0, 3), "phase2_s": round(t2 - t1, 3)}, out
+
+
+def cold_cli(names, seqs, contra):
+    """the drop-in itself: dafs_amd/dafs on the FASTA of the set, one cold process (start-up, context, code objects,
+    every allocation) -- what the reference's 30-45 s wall-clock compares with"""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "dafs_amd", "dafs")
+    if not os.path.exists(exe):
+        return None
+    with tempfile.NamedTemporaryFile("w", suffix=".fa", delete=False) as f:
+        for n, sq in zip(names, seqs):
+            f.write(">%s\n%s\n" % (n, sq))
+        path = f.name
+    cmd = [exe, "-s", "CONTRAfold", "--no-alifold"] + (["-a", "CONTRAlign"] if contra else []) + [path]
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    wall = time.perf_counter() - t0
+    os.unlink(path)
+    if r.returncode != 0:
+        return {"error": r.stderr.strip()[-200:]}
+    return {"wall_s": wall, "command": "dafs -s CONTRAfold --no-alifold%s FASTA" % (" -a CONTRAlign" if contra else ""), "stdout": r.stdout}
 
 
 def main():
@@ -83,23 +146,44 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3", help="BASELINE.json configuration (c3 = the metric's N=128, L~150)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="--gpus N > 1: strong = the same set on N GPUs (the metric), weak = a sqrt(N)-times larger set")
     ap.add_argument("--n-seq", type=int, default=0, help="override the number of sequences")
-    ap.add_argument("--length", type=int, default=BASE_L)
+    ap.add_argument("--length", type=int, default=0, help="override the nominal length")
     ap.add_argument("--th", type=float, default=0.01)
     ap.add_argument("--model", choices=("probcons", "contralign"), default="probcons", help="alignment model of the timed kernel")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end wall-clock leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end wall-clock legs (warm driver run, cold CLI, forced-iteration DD run)")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    from dafs_amd import capi
+    cfg_n, cfg_l = CONFIGS[args.config]
+    args.length = args.length or cfg_l
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, args.gpus))
+    contra = args.model == "contralign"
+    n_seq = args.n_seq or (int(round(cfg_n * math.sqrt(world))) if args.scaling == "weak" else cfg_n)
+    names, seqs, lens, px, py, total_pairs = build_shard(n_seq, args.length, world, rank)
+    np_local = len(px)
+
+    # ---- CPU legs first: they fork worker processes, which must happen before this process touches the GPU ----
+    cpu = cpu_e2e = cli = None
+    cpu_out = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(seqs, px, py, args.th, 1 if contra else 0, args.length)
+        if not args.no_e2e:
+            cpu_e2e, cpu_out = cpu_end_to_end(names, seqs, 1 if contra else 0)
+            cpu["end_to_end"] = cpu_e2e
+    if rank == 0 and world == 1 and not args.no_e2e:
+        cli = cold_cli(names, seqs, contra)  # a child process with a GPU context of its own
+
+    import torch
+    import torch.distributed as dist
+    from dafs_amd import capi
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -112,10 +196,6 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    n_seq = args.n_seq or int(round(BASE_N * math.sqrt(world)))
-    names, seqs, lens, px, py, total_pairs = build_shard(n_seq, args.length, world, rank)
-    np_local = len(px)
-
     # ---- device-resident inputs (torch = allocator + stream only) ----
     codes = np.concatenate([capi.encode(s) for s in seqs])
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
@@ -125,7 +205,6 @@ def main():
     rp_off = np.concatenate([[0], np.cumsum(rp_sizes)])[:-1].astype(np.uint64)
     rp_total = int(rp_sizes.sum())
     plan = capi.PairhmmPlan()
-    contra = args.model == "contralign"
     plan_fn, launch_fn = (capi.pairhmm5_plan, capi.pairhmm5_launch) if contra else (capi.pairhmm_plan, capi.pairhmm3_launch)
     capi.check(plan_fn(np_local, int(lens[px].max()), int(lens[py].max()), plan))
     pool_cap = int(2 * 24 * np.minimum(lens[px], lens[py]).sum())
@@ -248,27 +327,71 @@ def main():
     except Exception:  # noqa: BLE001
         traffic = None
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(seqs, px, py, args.th)
+    # ---- the timed call path against the oracle: a strided sample of the last launch's outputs, bit for bit ----
+    verified = 0
+    if rank == 0:
+        import oracle_lib
+        orc = oracle_lib.load_oracle()
+        o = sets[(nstep[0] - 1) % nsets]
+        h_nnz = o["pair_nnz"].cpu().numpy().view(np.uint32)
+        h_off = o["pair_off"].cpu().numpy().view(np.uint64)
+        h_sim = o["sim"].cpu().numpy()
+        h_rp = o["rowptr"].cpu().numpy().view(np.uint32)
+        for k in range(0, np_local, max(1, np_local // 48)):
+            x, y = int(px[k]), int(py[k])
+            l1 = int(lens[x])
+            n, base = int(h_nnz[k]), int(h_off[k])
+            col = o["col"][base:base + n].cpu().numpy().view(np.uint32)
+            val = o["val"][base:base + n].cpu().numpy()
+            rp = h_rp[int(rp_off[k]):int(rp_off[k]) + l1 + 1]
+            orp, ocol, oval = orc.align_calculate(seqs[x], seqs[y], args.th, 1 if contra else 0)
+            osim = orc.similarity(orp, ocol, oval, l1, int(lens[y]))
+            if not (np.array_equal(rp, orp) and np.array_equal(col, ocol) and val.tobytes() == oval.tobytes()
+                    and np.float32(h_sim[k]).tobytes() == np.float32(osim).tobytes()):
+                raise SystemExit("bench: pair (%d, %d) of the timed launch differs from the oracle" % (x, y))
+            verified += 1
 
     e2e = None
+    dd_forced = None
     if rank == 0 and world == 1 and not args.no_e2e:
         # BASELINE.json's second quantity: end-to-end wall-clock of the whole run (fold, pair posteriors,
         # consistency, tree, progressive DD, final structure) on the same set; not part of `value`.
         from dafs_amd import pipeline
+        model = capi.ALIGN_CONTRALIGN if contra else capi.ALIGN_PROBCONS
         ctx = capi.Context(local_rank)
         # skip_uncoupled_folds=False: every node runs all three subproblems of every iteration, as the reference does
         # (the drivers' default leaves out the folding DPs of nodes that no consensus base pair couples; same output)
-        pipeline.run(names, seqs, ctx=ctx, skip_uncoupled_folds=False)  # warm-up on the same set: device buffers at their final size, code objects loaded
+        pipeline.run(names, seqs, ctx=ctx, align_model=model, skip_uncoupled_folds=False)  # warm-up on the same set: device buffers at their final size, code objects loaded
         t0 = time.perf_counter()
-        res = pipeline.run(names, seqs, ctx=ctx, skip_uncoupled_folds=False)
+        res = pipeline.run(names, seqs, ctx=ctx, align_model=model, skip_uncoupled_folds=False)
         wall = time.perf_counter() - t0
         its = [v[0] for v in res.dd_log.values()]
-        e2e = {"wall_s": wall, "note": "second run on a warm context (buffers allocated, kernels loaded)", "flags": "-a ProbCons -s CONTRAfold --no-alifold (defaults otherwise)",
+        e2e = {"wall_s": wall, "note": "second run on a warm context through the Python driver (buffers allocated, kernels loaded)",
+               "flags": "-a %s -s CONTRAfold --no-alifold (defaults otherwise)" % ("CONTRAlign" if contra else "ProbCons"),
                "phases_s": {k: round(v, 4) for k, v in res.seconds.items()},
                "dd_iterations_total": int(np.sum(its)), "dd_iterations_max": int(np.max(its)), "tree_levels": res.levels,
                "columns": len(res.rows[0])}
+        if cli is not None and "wall_s" in cli:
+            e2e["cold_cli_wall_s"] = cli["wall_s"]
+            e2e["cold_cli"] = cli["command"] + ": one cold process (start-up, GPU context, code objects, allocations)"
+            e2e["cold_cli_output_equals_driver"] = cli["stdout"] == res.output
+        elif cli is not None:
+            e2e["cold_cli_error"] = cli.get("error")
+        if cpu_out is not None:
+            e2e["output_equals_cpu_port"] = cpu_out == res.output
+        # BASELINE.json config 3 ("600 subgradient iters"): every node runs t_max iterations (the violated == 0 exit is
+        # ignored), so the subproblem kernels are timed on a fixed amount of work
+        fr = pipeline.run(names, seqs, ctx=ctx, align_model=model, skip_uncoupled_folds=False, force_iters=1)
+        nit = int(np.sum([v[0] for v in fr.dd_log.values()]))
+        alg = 0.0
+        for i, (l1, l2) in fr.dd_dims.items():
+            alg += fr.dd_log[i][0] * (16.0 * (l1 * (l1 - 1) // 2 + l2 * (l2 - 1) // 2) + 13.0 * (l1 + 1) * (l2 + 1) + 64.0 * fr.dd_log[i][2])
+        sec = fr.seconds["progressive"]
+        dd_forced = {"node_iterations": nit, "nodes": len(fr.dd_log), "progressive_s": sec, "node_iterations_per_s": nit / sec,
+                     "algorithmic_bytes": alg, "achieved_GBps": alg / sec / 1e9, "frac_of_hbm_peak": alg / sec / 1e9 / HBM_PEAK_GBS,
+                     "note": "k_dd_solve, all nodes forced to t_max=600 iterations; per node-iteration 2*16*L(L-1)/2 + 13*(L1+1)(L2+1) + 64*#cbp "
+                             "algorithmic bytes, none of which crosses HBM for narrow nodes: the loop is latency-bound (one wavefront per "
+                             "subproblem), the guide tree serialises the nodes"}
         ctx.close()
 
     if rank == 0:
@@ -278,7 +401,7 @@ def main():
             "unit": "seq-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "N=%d L~%d synthetic random RNA (seed 12345), %d pairs%s" %
                                    (n_seq, args.length, total_pairs,
@@ -289,9 +412,12 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
+            "verified_pairs": verified,
         }
         if e2e is not None:
             out["end_to_end"] = e2e
+        if dd_forced is not None:
+            out["dd_forced_iterations"] = dd_forced
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

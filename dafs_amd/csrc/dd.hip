@@ -1141,7 +1141,16 @@ __device__ __noinline__ void dd_folder(const dd_node& nd, const dd_params& prm, 
 // the subgradient loop, dafs.cpp:1066-1294
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* nodes, dd_params prm, uint32_t* paused_out) {
-  const dd_node nd = nodes[blockIdx.x];
+  // The node descriptor (sixty-odd pointers) lives in LDS: as a private copy it went to scratch memory (568 bytes per
+  // lane, re-read from there a hundred times in the loop below), because the out-of-line helpers take it by reference.
+  __shared__ dd_node s_nd;
+  {
+    const uint32_t* src = (const uint32_t*)(nodes + blockIdx.x);
+    uint32_t* dst = (uint32_t*)&s_nd;
+    for (uint32_t k = threadIdx.x; k < sizeof(dd_node) / 4; k += blockDim.x) dst[k] = src[k];
+  }
+  __syncthreads();
+  const dd_node& nd = s_nd;
   if (blockIdx.y != 0) {  // folding workgroups of a split node
     if (nd.split) dd_folder(nd, prm, blockIdx.y, nd.info[6] != 0 ? nd.info[1] : 0u);
     return;

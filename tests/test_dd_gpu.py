@@ -206,3 +206,24 @@ def test_dense_base_pairs_overflow_the_register_form(oracle, monkeypatch):
     monkeypatch.setenv("DAFS_HIP_DD_SPLIT", "0")
     ref = pipeline.run(names, seqs, bp=bp, t_max=12, level_sync=True, skip_uncoupled_folds=False)
     assert ref.output == want and ref.dd_log == got.dd_log
+
+
+def test_forced_iterations_equal_oracle(oracle):
+    """force_iters (the bench mode that ignores the violated == 0 exit, dafs_dd_params / oracle pipeline.c:523): every
+    node runs t_max iterations; output and iteration log must still be the oracle's."""
+    from dafs_amd import pipeline
+    from test_pct_gpu import random_bp
+    recs = synth.family_set(7, 60, seed=31) + synth.random_set(2, 45, seed=32)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    bp = random_bp(seqs, 31, density=0.04)
+    for t_max in (1, 17):
+        pl = oracle.pipeline(names, seqs, oracle.params(fold_model=1, t_max=t_max, force_iters=1), bp=bp)
+        pl.phase1(); pl.phase2()
+        want = pl.output()
+        it, vi = pl.dd_log()
+        pl.close()
+        got = pipeline.run(names, seqs, bp=bp, t_max=t_max, force_iters=1, skip_uncoupled_folds=False)
+        assert got.output == want, t_max
+        assert [int(x) for x in it] == [t_max] * (len(seqs) - 1)
+        assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
+        assert sorted(v[1] for v in got.dd_log.values()) == sorted(int(x) for x in vi)
