@@ -89,6 +89,8 @@ _fold_posterior_dense = _sig("dafs_hip_fold_posterior_dense", C.c_int,
 _consistency = _sig("dafs_hip_consistency", C.c_int, [C.c_void_p, C.c_float, C.c_float])
 _consistency_match = _sig("dafs_hip_consistency_match", C.c_int, [C.c_void_p, C.c_float])
 _consistency_bp = _sig("dafs_hip_consistency_bp", C.c_int, [C.c_void_p, C.c_float])
+_consistency_match_range = _sig("dafs_hip_consistency_match_range", C.c_int, [C.c_void_p, C.c_float, C.c_uint64, C.c_uint64])
+_mp_install = _sig("dafs_hip_mp_install", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
 _fold_begin = _sig("dafs_hip_fold_posteriors_begin", C.c_int, [C.c_void_p, C.c_int, C.c_float])
 _fold_end = _sig("dafs_hip_fold_posteriors_end", C.c_int, [C.c_void_p])
 
@@ -180,6 +182,7 @@ class Context:
         self._h = C.c_void_p()
         check(_create(device, C.byref(self._h)))
         self._lens = None
+        self.device_index = device
 
     def close(self):
         if self._h:
@@ -279,6 +282,17 @@ class Context:
 
     def consistency_match(self, w_pct_a=0.25):
         check(_consistency_match(self._h, w_pct_a))
+
+    def consistency_match_range(self, w_pct_a, pair_begin, pair_end):
+        check(_consistency_match_range(self._h, w_pct_a, pair_begin, pair_end))
+
+    def mp_install(self, relaxed, nnz, rowptr, col, val, sim=None):
+        """a whole store from arrays in the layout of mp() / align_posteriors() results (dafs_hip_mp_install)"""
+        nnz = np.ascontiguousarray(nnz, np.uint32); rowptr = np.ascontiguousarray(rowptr, np.uint32)
+        col = np.ascontiguousarray(col, np.uint32); val = np.ascontiguousarray(val, np.float32)
+        sim = None if sim is None else np.ascontiguousarray(sim, np.float32)
+        check(_mp_install(self._h, relaxed, nnz.ctypes.data, rowptr.ctypes.data, col.ctypes.data if len(col) else None,
+                          val.ctypes.data if len(val) else None, None if sim is None else sim.ctypes.data))
 
     def consistency_bp(self, w_pct_s=0.25):
         check(_consistency_bp(self._h, w_pct_s))

@@ -255,6 +255,71 @@ extern "C" int dafs_hip_set_mp(dafs_hip_ctx* c, const uint32_t* nnz, const uint3
   return DAFS_HIP_OK;
 }
 
+// A complete matching-probability store from arrays in the layout dafs_hip_mp_fetch / dafs_hip_align_fetch write (all
+// pairs x < y in row-major order; per pair len_x+1 row pointers of mp[x][y] then len_y+1 of mp[y][x], relative to the
+// pair; per pair nnz entries of mp[x][y] then nnz of mp[y][x]): what the ranks of a multi-GPU run hold after gathering
+// their shards.  relaxed = 0 installs the models' posteriors together with the similarity scores sim[npairs]
+// (calculate_similarity_score of every pair, computed by the shard's kernel); relaxed = 1 installs the result of the
+// consistency transform on top of an installed or computed un-relaxed store.  Nothing is recomputed: uploads only.
+extern "C" int dafs_hip_mp_install(dafs_hip_ctx* c, int relaxed, const uint32_t* nnz, const uint32_t* rowptr, const uint32_t* col,
+                                   const float* val, const float* sim) {
+  if (!c || c->len.size() < 2 || relaxed < 0 || relaxed > 1 || !nnz || !rowptr) return DAFS_HIP_EINVAL;
+  if (relaxed == 0 && !sim) return DAFS_HIP_EINVAL;
+  if (relaxed == 1 && (!c->mp[0].valid || c->sim.empty())) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  const uint32_t n = (uint32_t)c->len.size();
+  const uint64_t np = (uint64_t)n * (n - 1) / 2;
+  mp_store& st = c->mp[relaxed];
+  st.valid = false;
+  if (relaxed == 0) { c->mp[1].valid = false; c->cur_mp = 0; c->sim.clear(); }
+  st.pair_x.resize(np); st.pair_y.resize(np); st.task_of_pair.resize(np); st.rp_by_pair.resize(np);
+  st.n_tasks = np;
+  std::vector<uint64_t> pair_off(np);
+  uint64_t rp_total = 0, ent_total = 0, p = 0;
+  for (uint32_t x = 0; x < n; ++x)
+    for (uint32_t y = x + 1; y < n; ++y, ++p) {
+      st.pair_x[p] = x; st.pair_y[p] = y; st.task_of_pair[p] = (uint32_t)p;
+      st.rp_by_pair[p] = rp_total;
+      pair_off[p] = ent_total;
+      const uint32_t* rp = rowptr + rp_total;
+      if (rp[0] != 0 || rp[c->len[x]] != nnz[p] || rp[c->len[x] + 1] != 0 || rp[c->len[x] + 1 + c->len[y]] != nnz[p]) return DAFS_HIP_EINVAL;
+      rp_total += (uint64_t)c->len[x] + 1 + c->len[y] + 1;
+      ent_total += 2ull * nnz[p];
+    }
+  if (ent_total && (!col || !val)) return DAFS_HIP_EINVAL;
+  int rc;
+  st.rp_total = rp_total;
+  st.pool_used = ent_total;
+  st.pool_cap_hint = std::max<uint64_t>(st.pool_cap_hint, ent_total);
+  if ((rc = st.rowptr_pool.upload(rowptr, rp_total, c->stream))) return rc;
+  if ((rc = st.col.reserve(ent_total + 1))) return rc;
+  if ((rc = st.val.reserve(ent_total + 1))) return rc;
+  if (ent_total) {
+    if ((rc = st.col.upload(col, ent_total, c->stream))) return rc;
+    if ((rc = st.val.upload(val, ent_total, c->stream))) return rc;
+  }
+  if ((rc = st.pair_off.upload(pair_off.data(), np, c->stream))) return rc;
+  if ((rc = st.pair_nnz.upload(nnz, np, c->stream))) return rc;
+  if ((rc = st.rp_off.upload(st.rp_by_pair.data(), np, c->stream))) return rc;
+  if ((rc = st.d_task_of_pair.upload(st.task_of_pair.data(), np, c->stream))) return rc;
+  if ((rc = c->d_pair_x.upload(st.pair_x.data(), np, c->stream))) return rc;
+  if ((rc = c->d_pair_y.upload(st.pair_y.data(), np, c->stream))) return rc;
+  if (relaxed == 0) {
+    c->sim.assign((size_t)n * n, 0.0f);
+    for (uint32_t i = 0; i < n; ++i) c->sim[(size_t)i * n + i] = 1.0f;
+    for (p = 0; p < np; ++p) {
+      c->sim[(size_t)st.pair_x[p] * n + st.pair_y[p]] = sim[p];
+      c->sim[(size_t)st.pair_y[p] * n + st.pair_x[p]] = sim[p];
+    }
+    if ((rc = c->d_sim.upload(c->sim.data(), c->sim.size(), c->stream))) return rc;
+    if ((rc = c->task_sim.upload(sim, np, c->stream))) return rc;
+  } else {
+    c->cur_mp = 1;
+  }
+  st.valid = true;
+  return DAFS_HIP_OK;
+}
+
 extern "C" int dafs_hip_mp_result_size(dafs_hip_ctx* c, int relaxed, uint64_t* npairs, uint64_t* total_nnz, uint64_t* total_rowptr) {
   if (!c || relaxed < 0 || relaxed > 1 || !c->mp[relaxed].valid) return DAFS_HIP_EINVAL;
   const mp_store& st = c->mp[relaxed];

@@ -80,7 +80,7 @@ extern "C" int dafs_hip_bp_fetch(dafs_hip_ctx* c, int relaxed, uint32_t* rowptr,
 // stores (dafs.cpp:1822-1827).  A weight of 0 skips that transform, as the reference does.
 // which: bit 0 the base-pairing transform, bit 1 the matching transform (the two read only un-relaxed stores, so they
 // may be run in either order, e.g. the matching transform while the folding kernels are still busy)
-static int consistency_parts(dafs_hip_ctx* c, float w_pct_a, float w_pct_s, int which) {
+static int consistency_parts(dafs_hip_ctx* c, float w_pct_a, float w_pct_s, int which, uint64_t pair_begin = 0, uint64_t pair_end = 0) {
   if (!c || c->len.empty()) return DAFS_HIP_EINVAL;
   if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
   const uint32_t n = (uint32_t)c->len.size();
@@ -91,6 +91,9 @@ static int consistency_parts(dafs_hip_ctx* c, float w_pct_a, float w_pct_s, int 
   const mp_store_dev mpv = raw.view(c->d_len.ptr, n);
   int rc;
   if ((rc = c->counters.reserve(4))) return rc;
+  if (pair_end == 0) pair_end = all;
+  if (pair_begin > pair_end || pair_end > all) return DAFS_HIP_EINVAL;
+  const bool shard = pair_begin != 0 || pair_end != all;  // only these output pairs are computed, the others stay empty
 
   if (which & 1) c->cur_bp = 0;
   if ((which & 1) && w_pct_s != 0.0f) {
@@ -159,6 +162,11 @@ static int consistency_parts(dafs_hip_ctx* c, float w_pct_a, float w_pct_s, int 
       if ((rc = out.col.reserve(cap))) return rc;
       if ((rc = out.val.reserve(cap))) return rc;
       if (hip_check(hipMemsetAsync(c->counters.ptr, 0, 4 * sizeof(unsigned long long), c->stream))) return DAFS_HIP_ELAUNCH;
+      if (shard) {  // pairs outside the shard: no entries, all row pointers 0
+        if (hip_check(hipMemsetAsync(out.rowptr_pool.ptr, 0, out.rp_total * sizeof(uint32_t), c->stream))) return DAFS_HIP_ELAUNCH;
+        if (hip_check(hipMemsetAsync(out.pair_off.ptr, 0, all * sizeof(uint64_t), c->stream))) return DAFS_HIP_ELAUNCH;
+        if (hip_check(hipMemsetAsync(out.pair_nnz.ptr, 0, all * sizeof(uint32_t), c->stream))) return DAFS_HIP_ELAUNCH;
+      }
       pct_match_args a;
       memset(&a, 0, sizeof a);
       a.in = mpv; a.sim = c->d_sim.ptr; a.pair_x = c->d_pair_x.ptr; a.pair_y = c->d_pair_y.ptr;
@@ -168,10 +176,10 @@ static int consistency_parts(dafs_hip_ctx* c, float w_pct_a, float w_pct_s, int 
       a.status = (int*)(c->counters.ptr + 2);
       // dense row tiles, in batches of at most kTileFloats; the tile memory is the pair kernels' scratch
       const uint64_t kTileFloats = 1ull << 31;  // 8 GiB
-      for (uint64_t p0 = 0; p0 < all;) {
+      for (uint64_t p0 = pair_begin; p0 < pair_end;) {
         std::vector<uint64_t> toff;
         uint64_t cells = 0, p1 = p0;
-        while (p1 < all) {
+        while (p1 < pair_end) {
           const uint64_t need = (uint64_t)c->len[raw.pair_x[p1]] * c->len[raw.pair_y[p1]];
           if (p1 > p0 && cells + need > kTileFloats) break;
           toff.push_back(cells);
@@ -204,3 +212,10 @@ static int consistency_parts(dafs_hip_ctx* c, float w_pct_a, float w_pct_s, int 
 extern "C" int dafs_hip_consistency(dafs_hip_ctx* c, float w_pct_a, float w_pct_s) { return consistency_parts(c, w_pct_a, w_pct_s, 3); }
 extern "C" int dafs_hip_consistency_match(dafs_hip_ctx* c, float w_pct_a) { return consistency_parts(c, w_pct_a, 0.0f, 2); }
 extern "C" int dafs_hip_consistency_bp(dafs_hip_ctx* c, float w_pct_s) { return consistency_parts(c, 0.0f, w_pct_s, 1); }
+// The matching transform for the output pairs [pair_begin, pair_end) only (row-major pair index; every output pair
+// reads all the un-relaxed matrices, none reads another output: dafs.cpp:265-315).  The other pairs of the relaxed
+// store stay empty; a multi-GPU run gathers the shards and installs the whole with dafs_hip_mp_install.
+extern "C" int dafs_hip_consistency_match_range(dafs_hip_ctx* c, float w_pct_a, uint64_t pair_begin, uint64_t pair_end) {
+  if (w_pct_a == 0.0f) return DAFS_HIP_EINVAL;
+  return consistency_parts(c, w_pct_a, 0.0f, 2, pair_begin, pair_end);
+}

@@ -1,4 +1,11 @@
-"""Multi-GPU plumbing of the pair-posterior phase: pair-index sharding and the one all-gather.
+"""Multi-GPU plumbing: pair-index sharding and the gathers of the sparse posteriors.
+
+Two users.  bench.py times phase 1 at the L0 (device pointer) level: cost-sorted deal of the pair jobs
+(shard_pairs) and ONE all-gather of a packed slab per step (ShardExchange).  phase1_sharded is the whole
+sharded phase 1 of a run on top of the L1 C ABI: folds by x mod G, pair posteriors and the matching
+consistency transform by contiguous pair-index ranges, each followed by a gather; after it every rank's
+context holds the complete stores and the rest of the run (guide tree, progressive phase) is replicated
+(phase 2 is tree-sequential).
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU
 tests).  The N(N-1)/2 pair jobs are independent: they are sorted by cost and dealt round-robin to the
@@ -87,7 +94,10 @@ class GatheredPairs:
 
 
 class ShardExchange:
-    """Pre-sized slabs for the all-gather of one shard's outputs (sizes exchanged once up front)."""
+    """The one exchange of phase 1 at the L0 level: every rank's {per-pair nnz / sim / pool offset, row pointers,
+    entry columns, entry values} travel as ONE packed int32 slab in ONE all-gather (fixed strides agreed once up
+    front; a rank whose parts are shorter pads).  Slab of rank r: [4 * s_pairs meta | s_rp row pointers | s_pool
+    columns | s_pool values (bits)]."""
 
     def __init__(self, dist, device, world, n_pairs_local, rp_total_local, pool_cap_local):
         import torch
@@ -96,42 +106,154 @@ class ShardExchange:
         dist.all_reduce(sizes, op=dist.ReduceOp.MAX)
         self.s_pairs, self.s_rp, self.s_pool_cap = [int(v) for v in sizes.tolist()]
         self.n_pairs, self.rp_total = n_pairs_local, rp_total_local
-        self.send_meta = torch.zeros(self.s_pairs * 4, dtype=torch.int32, device=device)
-        self.send_rp = torch.zeros(self.s_rp, dtype=torch.int32, device=device)
-        self.recv_meta = torch.empty(world * self.s_pairs * 4, dtype=torch.int32, device=device)
-        self.recv_rp = torch.empty(world * self.s_rp, dtype=torch.int32, device=device)
-        self.recv_col = self.recv_val = None
         self.s_pool = 0
+        self.send = self.recv = None
+
+    def _layout(self):
+        m, r, c = 4 * self.s_pairs, self.s_rp, self.s_pool
+        return m, r, c, m + r + 2 * c
 
     def exchange(self, pair_nnz, sim, pair_off, rowptr, col, val, pool_used):
         """pair_nnz int32[n], sim float32[n], pair_off int64[n], rowptr int32[rp_total], col int32[cap],
         val float32[cap] (all on self.device); pool_used = entries this rank produced (None: as in the previous
-        call).  One max-reduce for the payload stride, then the gather itself."""
+        call).  One max-reduce for the payload stride the first time, then the gather itself."""
         torch, dist = self.torch, self.dist
-        if pool_used is not None or self.s_pool == 0:
+        if pool_used is None and self.s_pool == 0:
+            raise ValueError("ShardExchange.exchange: the first call needs pool_used (the payload stride is agreed from it)")
+        if pool_used is not None:
             mx = torch.tensor([int(pool_used)], dtype=torch.int64, device=self.device)
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
             self.s_pool = int(mx.item())
         # pool_used=None: a repeat of an exchange whose sizes are known (same inputs): the stride agreed then is
         # reused and nothing in this call waits for the device
-        m = self.send_meta.view(self.s_pairs, 4)
-        m[:self.n_pairs, 0] = pair_nnz
-        m[:self.n_pairs, 1] = sim.view(torch.int32)
-        m[:self.n_pairs, 2:4] = pair_off.view(torch.int32).view(self.n_pairs, 2)
-        self.send_rp[:self.rp_total] = rowptr[:self.rp_total]
-        if self.recv_col is None or self.recv_col.numel() != self.world * self.s_pool:
-            self.recv_col = torch.empty(self.world * self.s_pool, dtype=torch.int32, device=self.device)
-            self.recv_val = torch.empty(self.world * self.s_pool, dtype=torch.float32, device=self.device)
-        send_col, send_val = col[:self.s_pool], val[:self.s_pool]
-        if send_col.numel() < self.s_pool:  # this rank's pool is shorter than the longest: pad
-            send_col = torch.cat([send_col, torch.zeros(self.s_pool - send_col.numel(), dtype=torch.int32, device=self.device)])
-            send_val = torch.cat([send_val, torch.zeros(self.s_pool - send_val.numel(), dtype=torch.float32, device=self.device)])
-        dist.all_gather_into_tensor(self.recv_meta, self.send_meta)
-        dist.all_gather_into_tensor(self.recv_rp, self.send_rp)
-        dist.all_gather_into_tensor(self.recv_col, send_col.contiguous())
-        dist.all_gather_into_tensor(self.recv_val, send_val.contiguous())
+        m, r, c, total = self._layout()
+        if self.send is None or self.send.numel() != total:
+            self.send = torch.zeros(total, dtype=torch.int32, device=self.device)
+            self.recv = torch.empty(self.world * total, dtype=torch.int32, device=self.device)
+        meta = self.send[:m].view(self.s_pairs, 4)
+        meta[:self.n_pairs, 0] = pair_nnz
+        meta[:self.n_pairs, 1] = sim.view(torch.int32)
+        meta[:self.n_pairs, 2:4] = pair_off.view(torch.int32).view(self.n_pairs, 2)
+        self.send[m:m + self.rp_total] = rowptr[:self.rp_total]
+        k = min(c, col.numel())
+        self.send[m + r:m + r + k] = col[:k]
+        self.send[m + r + c:m + r + c + k] = val[:k].view(torch.int32)
+        dist.all_gather_into_tensor(self.recv, self.send)
 
     def gathered(self, lens):
-        return GatheredPairs(lens, self.world, self.recv_meta.cpu().numpy(), self.recv_rp.cpu().numpy().view(np.uint32),
-                             self.recv_col.cpu().numpy().view(np.uint32), self.recv_val.cpu().numpy(),
-                             (self.s_pairs, self.s_rp, self.s_pool))
+        m, r, c, total = self._layout()
+        rows = self.recv.cpu().numpy().reshape(self.world, total)
+        meta = np.ascontiguousarray(rows[:, :m]).reshape(-1)
+        rp = np.ascontiguousarray(rows[:, m:m + r]).reshape(-1).view(np.uint32)
+        col = np.ascontiguousarray(rows[:, m + r:m + r + c]).reshape(-1).view(np.uint32)
+        val = np.ascontiguousarray(rows[:, m + r + c:]).reshape(-1).view(np.float32)
+        return GatheredPairs(lens, self.world, meta, rp, col, val, (self.s_pairs, self.s_rp, self.s_pool))
+
+
+# ---------------------------------------------------------------------------------------------
+# sharded phase 1 of a whole run (L1 C ABI + torch.distributed; gloo in the tests, nccl = RCCL on a node)
+# ---------------------------------------------------------------------------------------------
+def _comm_device(dist, device):
+    import torch
+    return device if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def allgather_concat(dist, arr, device):
+    """concatenation over ranks (in rank order) of 1-D numpy arrays of different lengths: one size exchange, one
+    all-gather of max-padded rows"""
+    import torch
+    arr = np.ascontiguousarray(arr)
+    world = dist.get_world_size()
+    dev = _comm_device(dist, device)
+    n = torch.tensor([arr.size], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(v.item()) for v in sizes]
+    mx = max(sizes + [1])
+    raw = np.zeros(mx * arr.itemsize, np.uint8)
+    raw[:arr.nbytes] = arr.view(np.uint8).reshape(-1)
+    send = torch.from_numpy(raw).to(dev)
+    recv = torch.empty(world * raw.size, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    rows = recv.cpu().numpy().reshape(world, raw.size)
+    return np.concatenate([rows[r, :sizes[r] * arr.itemsize].view(arr.dtype) for r in range(world)])
+
+
+def allreduce_sum(dist, arr, device):
+    """elementwise sum over ranks of equally shaped integer arrays (shards that are zero outside their own part)"""
+    import torch
+    dev = _comm_device(dist, device)
+    t = torch.from_numpy(np.ascontiguousarray(arr).astype(np.int64)).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy().astype(arr.dtype)
+
+
+def pair_ranges(npairs, world):
+    """contiguous row-major pair-index ranges, one per rank (what dafs_hip_align_posteriors takes)"""
+    return [npairs * k // world for k in range(world + 1)]
+
+
+def phase1_sharded(ctx, seqs, dist, device, align_model, th_a, w_pct_a, w_pct_s, fold_th=0.01):
+    """Phase 1 of DAFS::run (dafs.cpp:1787-1827) on `world` ranks, one context (one GPU) each:
+      * base-pairing posteriors of the sequences x = rank (mod world), gathered and set on every rank (set_bp);
+      * pair posteriors + similarity scores of this rank's pair-index range, gathered, installed (mp_install);
+      * relax_matching_probability for this rank's range of OUTPUT pairs, gathered, installed as the relaxed store;
+      * relax_basepairing_probability replicated (milliseconds).
+    Afterwards ctx is in the state a single-GPU phase 1 leaves it in, bit for bit."""
+    from . import capi
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n = len(seqs)
+    npairs = n * (n - 1) // 2
+    ctx.set_sequences(seqs)
+    # ---- folds: x = rank mod world, in a context of their own; rows gathered as three flat arrays ----
+    mine = list(range(rank, n, world))
+    rows = []
+    if mine:
+        fc = capi.Context(ctx.device_index)
+        try:
+            fc.set_sequences([seqs[x] for x in mine])
+            fc.fold_posteriors(fold_th)
+            rows = fc.bp(0)
+        finally:
+            fc.close()
+    rp = allgather_concat(dist, np.concatenate([r[0] for r in rows]) if rows else np.zeros(0, np.uint32), device)
+    col = allgather_concat(dist, np.concatenate([r[1] for r in rows]) if rows else np.zeros(0, np.uint32), device)
+    val = allgather_concat(dist, np.concatenate([r[2] for r in rows]) if rows else np.zeros(0, np.float32), device)
+    order = [x for r in range(world) for x in range(r, n, world)]  # sequence of the k-th gathered row block
+    all_rows = [None] * n
+    r0 = e0 = 0
+    for x in order:
+        L = len(seqs[x])
+        r = rp[r0:r0 + L + 1]
+        k = int(r[-1])
+        all_rows[x] = (r, col[e0:e0 + k], val[e0:e0 + k])
+        r0 += L + 1
+        e0 += k
+    ctx.set_bp(all_rows)
+    # ---- pair posteriors of [b0, b1): concatenating the ranks' arrays in rank order IS the whole in pair order ----
+    b = pair_ranges(npairs, world)
+    res = ctx.align_posteriors(align_model, th_a, pair_begin=b[rank], pair_end=b[rank + 1]) if b[rank + 1] > b[rank] else None
+    z32, zf = np.zeros(0, np.uint32), np.zeros(0, np.float32)
+    nnz = allgather_concat(dist, res.nnz if res else z32, device)
+    rowptr = allgather_concat(dist, res._rowptr if res else z32, device)
+    col = allgather_concat(dist, res._col if res else z32, device)
+    val = allgather_concat(dist, res._val if res else zf, device)
+    sim = allgather_concat(dist, res.sim if res else zf, device)
+    ctx.mp_install(0, nnz, rowptr, col, val, sim)
+    # ---- consistency: matching transform sharded by output pair, base-pairing transform replicated ----
+    if w_pct_a != 0.0:
+        if b[rank + 1] > b[rank]:
+            ctx.consistency_match_range(w_pct_a, b[rank], b[rank + 1])
+            part = ctx.mp(1)
+            p_nnz, p_rp, p_col, p_val = part.nnz, part._rowptr, part._col, part._val
+        else:
+            lens = np.array([len(s) for s in seqs], np.int64)
+            ii, jj = np.triu_indices(n, k=1)
+            p_nnz, p_rp, p_col, p_val = np.zeros(npairs, np.uint32), np.zeros(int((lens[ii] + lens[jj] + 2).sum()), np.uint32), z32, zf
+        nnz = allreduce_sum(dist, p_nnz, device)      # zero outside the shard
+        rowptr = allreduce_sum(dist, p_rp, device)
+        col = allgather_concat(dist, p_col, device)   # shard entries only, shards are in pair order
+        val = allgather_concat(dist, p_val, device)
+        ctx.mp_install(1, nnz, rowptr, col, val)
+    if w_pct_s != 0.0:
+        ctx.consistency_bp(w_pct_s)

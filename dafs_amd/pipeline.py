@@ -88,15 +88,33 @@ class Result:
 
 def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25, w_pct_s=0.25, th_a=0.01,
         th_s=0.2, th_s1=None, align_model=capi.ALIGN_PROBCONS, force_iters=0, timers=None, level_sync=False, slice_iters=32,
-        mp=None, skip_uncoupled_folds=True):
+        mp=None, skip_uncoupled_folds=True, shard=None):
     """The whole run.  bp: per-sequence (rowptr, col, val) base-pairing rows (--fold-aux); None
-    computes them with the device fold model.  mp: supplied matching probabilities (--align-aux), see Context.set_mp."""
+    computes them with the device fold model.  mp: supplied matching probabilities (--align-aux), see Context.set_mp.
+    shard: (torch.distributed module, torch device) of an initialised process group -- phase 1 (folds, pair posteriors,
+    matching consistency transform) is then split over the ranks and gathered (dist.phase1_sharded); every rank
+    finishes the run and holds the same result."""
     import time
     own = ctx is None
     if own:
         ctx = capi.Context(0)
     t = [time.perf_counter()]
     n = len(seqs)
+    if shard is not None:
+        from . import dist as ddist
+        ddist.phase1_sharded(ctx, seqs, shard[0], shard[1], align_model, th_a, w_pct_a, w_pct_s)
+        t += [time.perf_counter()] * 2
+        sim = ctx.sim()
+    else:
+        sim = _phase1_local(ctx, seqs, bp, mp, align_model, th_a, w_pct_a, w_pct_s, t)
+    score, left, right = capi.build_tree(sim)  # same code as the command line (build_tree below is its Python twin, kept for the CPU tests)
+    t.append(time.perf_counter())
+    return _phase2(ctx, own, names, seqs, n, sim, score, left, right, t, w, eta0, t_max, th_a, th_s, th_s1, force_iters, level_sync, slice_iters,
+                   skip_uncoupled_folds)
+
+
+def _phase1_local(ctx, seqs, bp, mp, align_model, th_a, w_pct_a, w_pct_s, t):
+    import time
     ctx.set_sequences(seqs)
     # The folding (one workgroup per sequence) leaves most of the device idle, and nothing before the base-pair
     # transform needs its result: it is started on its own stream, and the all-pairs alignment posteriors and the
@@ -116,8 +134,12 @@ def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25
     if bp is None:
         ctx.fold_end()
     ctx.consistency_bp(w_pct_s)
-    score, left, right = capi.build_tree(sim)  # same code as the command line (build_tree below is its Python twin, kept for the CPU tests)
-    t.append(time.perf_counter())
+    return sim
+
+
+def _phase2(ctx, own, names, seqs, n, sim, score, left, right, t, w, eta0, t_max, th_a, th_s, th_s1, force_iters, level_sync, slice_iters,
+            skip_uncoupled_folds):
+    import time
     res = Result()
     res.sim = sim
     res.tree = (score, left, right)

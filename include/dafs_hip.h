@@ -180,7 +180,13 @@ int dafs_hip_mp_fetch(dafs_hip_ctx* ctx, int relaxed, uint32_t* pair_x, uint32_t
  * concatenated.  Lays out the transposes (transpose_mp, src/dafs.cpp:155-167) and computes the similarity scores
  * (calculate_similarity_score, :713-764) on the device. */
 int dafs_hip_set_mp(dafs_hip_ctx* ctx, const uint32_t* nnz, const uint32_t* rowptr, const uint32_t* col, const float* val);
-/* sim_ (src/dafs.cpp:1813-1819): N*N floats, unit diagonal; needs a full-pair-set align_posteriors or dafs_hip_set_mp. */
+/* A whole store from arrays in the layout of dafs_hip_mp_fetch / dafs_hip_align_fetch (both directions of every pair; no
+ * recomputation, uploads only): how the ranks of a multi-GPU run take their gathered shards back in.  relaxed = 0: the
+ * models' posteriors, with sim[npairs] = the similarity score of every pair (src/dafs.cpp:763) as the shard kernels
+ * computed them; relaxed = 1: the consistency transform's result, on top of an un-relaxed store (sim may be NULL). */
+int dafs_hip_mp_install(dafs_hip_ctx* ctx, int relaxed, const uint32_t* nnz, const uint32_t* rowptr, const uint32_t* col,
+                        const float* val, const float* sim);
+/* sim_ (src/dafs.cpp:1813-1819): N*N floats, unit diagonal; needs a full-pair-set align_posteriors, dafs_hip_set_mp or dafs_hip_mp_install. */
 int dafs_hip_get_sim(dafs_hip_ctx* ctx, float* sim);
 
 /* ------------------------------------------------------------------------------------------
@@ -225,6 +231,10 @@ int dafs_hip_consistency(dafs_hip_ctx* ctx, float w_pct_a, float w_pct_s);
 /* the two transforms separately (each reads un-relaxed stores only) */
 int dafs_hip_consistency_match(dafs_hip_ctx* ctx, float w_pct_a);
 int dafs_hip_consistency_bp(dafs_hip_ctx* ctx, float w_pct_s);
+/* relax_matching_probability for the output pairs [pair_begin, pair_end) of the row-major pair enumeration only (every
+ * output pair is independent of the others, src/dafs.cpp:265-315): the shard of one rank of a multi-GPU run.  The
+ * other pairs of the relaxed store stay empty until the gathered whole is installed with dafs_hip_mp_install. */
+int dafs_hip_consistency_match_range(dafs_hip_ctx* ctx, float w_pct_a, uint64_t pair_begin, uint64_t pair_end);
 
 /* ------------------------------------------------------------------------------------------
  * L1: decoder plugins on dense row-major matrices (host buffers).

@@ -133,3 +133,50 @@ def test_two_rank_all_gather_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _worker_gathers(rank, world, port, q):
+    """the gather helpers of dist.phase1_sharded on ragged inputs (an empty contribution included)"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from dafs_amd import dist as dd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        parts = [np.arange(5, dtype=np.uint32) * 3, np.zeros(0, np.uint32), np.array([7, 9], np.uint32)][:world]
+        got = dd.allgather_concat(dist, parts[rank], dev)
+        assert got.dtype == np.uint32 and np.array_equal(got, np.concatenate(parts))
+        fparts = [np.array([0.5, -2.0], np.float32), np.array([1e-9], np.float32), np.zeros(0, np.float32)][:world]
+        got = dd.allgather_concat(dist, fparts[rank], dev)
+        assert got.dtype == np.float32 and got.tobytes() == np.concatenate(fparts).tobytes()
+        full = np.zeros(11, np.uint32)
+        lo, hi = dd.pair_ranges(11, world)[rank], dd.pair_ranges(11, world)[rank + 1]
+        full[lo:hi] = np.arange(lo, hi) + 100
+        s = dd.allreduce_sum(dist, full, dev)
+        assert s.dtype == np.uint32 and np.array_equal(s, np.arange(11) + 100)
+        b = dd.pair_ranges(21, world)
+        assert b[0] == 0 and b[-1] == 21 and all(b[k] <= b[k + 1] for k in range(world))
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ragged_gathers_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_gathers, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res

@@ -1,0 +1,69 @@
+"""The sharded run on real hardware: two (and three) ranks, one process each, all on the one GPU of the box (gloo
+carries the gathers; on a node the same code runs one rank per GPU over RCCL).  Phase 1 is split -- folds by x mod G,
+pair posteriors and the matching consistency transform by pair-index range -- gathered and installed, the rest of
+the run is replicated.  Every rank must end with the output of the single-process run, bit for bit."""
+import os
+import socket
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, model, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from dafs_amd import capi, pipeline, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        recs = synth.family_set(7, 60, seed=41) + synth.random_set(4, 50, seed=42)
+        names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+        ctx = capi.Context(0)
+        res = pipeline.run(names, seqs, ctx=ctx, align_model=model, shard=(dist, torch.device("cuda", 0)))
+        sim = ctx.sim()
+        ctx.close()
+        q.put((rank, res.output, sim.tobytes()))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAILED " + traceback.format_exc(), b""))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,model", [(2, 0), (3, 1)])
+def test_sharded_run_equals_single_process(world, model):
+    import torch.multiprocessing as mp
+    from dafs_amd import capi, pipeline, synth
+    recs = synth.family_set(7, 60, seed=41) + synth.random_set(4, 50, seed=42)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    ctx = capi.Context(0)
+    want = pipeline.run(names, seqs, ctx=ctx, align_model=model)
+    want_sim = ctx.sim().tobytes()
+    ctx.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker, args=(r, world, port, model, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in res) == list(range(world))
+    for rank, out, sim in res:
+        assert not out.startswith("FAILED"), out
+        assert out == want.output, rank
+        assert sim == want_sim, rank
