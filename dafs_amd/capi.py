@@ -115,6 +115,10 @@ _nussinov_decode = _sig("dafs_hip_nussinov_decode", C.c_int,
 _nw_envelope = _sig("dafs_hip_nw_envelope", C.c_int, [C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p])
 _nw_decode = _sig("dafs_hip_nw_decode", C.c_int,
                   [C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)])
+_nussinov_decode_dense = _sig("dafs_hip_nussinov_decode_dense", C.c_int,
+                              [C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)])
+_nw_decode_dense = _sig("dafs_hip_nw_decode_dense", C.c_int,
+                        [C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)])
 _make_brackets = _sig("dafs_hip_make_brackets", None, [C.c_uint32, C.c_void_p, C.c_char_p])
 _dd_default_params = _sig("dafs_hip_dd_default_params", None, [C.POINTER(DDParams)])
 _solve_nodes = _sig("dafs_hip_solve_nodes", C.c_int,
@@ -307,6 +311,23 @@ class Context:
         check(_nussinov_decode(self._h, th, w, L, p.ctypes.data, None if qq is None else qq.ctypes.data,
                                ss.ctypes.data, C.byref(score)))
         return np.float32(score.value), ss
+
+    def nussinov_dense(self, p, q, th, w=0.0):
+        """the dense Nussinov class (q None: the final-decode overload); returns (score, ss)"""
+        p = np.ascontiguousarray(p, np.float32)
+        q = None if q is None else np.ascontiguousarray(q, np.float32)
+        ss = np.zeros(p.shape[0], np.uint32)
+        s = C.c_float()
+        check(_nussinov_decode_dense(self._h, th, w, p.shape[0], p.ctypes.data, None if q is None else q.ctypes.data, ss.ctypes.data, C.byref(s)))
+        return np.float32(s.value), ss
+
+    def nw_dense(self, p, q, th):
+        p = np.ascontiguousarray(p, np.float32)
+        q = None if q is None else np.ascontiguousarray(q, np.float32)
+        al = np.zeros(p.shape[0], np.uint32)
+        s = C.c_float()
+        check(_nw_decode_dense(self._h, th, p.shape[0], p.shape[1], p.ctypes.data, None if q is None else q.ctypes.data, al.ctypes.data, C.byref(s)))
+        return np.float32(s.value), al
 
     def nw_envelope(self, p, th):
         p = np.ascontiguousarray(p, np.float32)

@@ -124,6 +124,51 @@ extern "C" int dafs_hip_nw_decode(dafs_hip_ctx* c, float th, uint32_t L1, uint32
   return nw_common(c, th, L1, L2, p, q, (uint32_t*)env, 0, 1, al, score);
 }
 
+// The dense decoder classes (reference Nussinov, src/nussinov.cpp:32-204, and NeedlemanWunsch,
+// src/needleman_wunsch.cpp:28-196; DAFS itself instantiates the sparse ones, src/dafs.cpp:1692,1759).
+extern "C" int dafs_hip_nussinov_decode_dense(dafs_hip_ctx* c, float th, float w, uint32_t L, const float* p, const float* q,
+                                              uint32_t* ss, float* score) {
+  if (!c || !p || !ss || L == 0) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  const size_t LL = (size_t)L * L;
+  carver cv;
+  for (int pass = 0; pass < 2; ++pass) {
+    cv.used = 0;
+    float* d_p = cv.take<float>(LL);
+    float* d_q = q ? cv.take<float>(LL) : nullptr;
+    float* d_dp = cv.take<float>(LL + 1);
+    uint32_t* d_tr = cv.take<uint32_t>(LL + 1);
+    uint32_t* d_stack = cv.take<uint32_t>(4 * ((size_t)L + 4));
+    uint32_t* d_ss = cv.take<uint32_t>(L);
+    float* d_score = cv.take<float>(1);
+    if (pass == 0) {
+      int rc = c->work.reserve(cv.used + 256);
+      if (rc) return rc;
+      cv.base = c->work.ptr;
+      continue;
+    }
+    if (hip_check(hipMemcpyAsync(d_p, p, LL * 4, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
+    if (q && hip_check(hipMemcpyAsync(d_q, q, LL * 4, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
+    int rc = nussinov_dense_launch(L, d_p, d_q, w, th, d_dp, d_tr, d_stack, d_ss, d_score, c->stream);
+    if (rc) return rc;
+    if (hip_check(hipMemcpyAsync(ss, d_ss, (size_t)L * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+    float s = 0;
+    if (hip_check(hipMemcpyAsync(&s, d_score, 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+    if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
+    if (score) *score = s;
+  }
+  return DAFS_HIP_OK;
+}
+
+// NeedlemanWunsch::decode = the sparse decoder's DP with every cell inside the envelope
+extern "C" int dafs_hip_nw_decode_dense(dafs_hip_ctx* c, float th, uint32_t L1, uint32_t L2, const float* p, const float* q,
+                                        uint32_t* al, float* score) {
+  if (!al || !L1 || !L2) return DAFS_HIP_EINVAL;
+  std::vector<uint32_t> env(2 * ((size_t)L1 + 1));
+  for (uint32_t i = 0; i <= L1; ++i) { env[2 * i] = i ? 1u : 0u; env[2 * i + 1] = L2; }
+  return nw_common(c, th, L1, L2, p, q, env.data(), 0, 1, al, score);
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-node solver
 // ---------------------------------------------------------------------------------------------

@@ -88,6 +88,8 @@ static const size_t kDdLdsBudget = 156 * 1024;  // dynamic LDS of k_dd_solve (th
 int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, bool split, uint32_t* d_paused, hipStream_t st);
 // standalone decoders on dense device matrices (one workgroup each)
 int nussinov_launch(uint32_t L, const float* p, const float* q, float w, float th, nuss_ws ws, uint32_t* ss, float* score, hipStream_t st);
+int nussinov_dense_launch(uint32_t L, const float* p, const float* q, float w, float th, float* dp, uint32_t* tr, uint32_t* stack, uint32_t* ss,
+                          float* score, hipStream_t st);
 int nw_launch(uint32_t L1, uint32_t L2, const float* p, const float* q, float th, uint32_t* env, int compute_env,
               float* dp, uint8_t* tr, uint32_t* al, float* score, hipStream_t st);
 

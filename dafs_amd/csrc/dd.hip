@@ -704,6 +704,59 @@ __global__ __launch_bounds__(DD_THREADS) void k_nussinov_single(uint32_t L, cons
   }
 }
 
+// Nussinov::decode, the dense class (reference src/nussinov.cpp:32-113 with q, :115-204 without): every pair scores
+// sm = w(p-th)-q (or p-th), and the bifurcation runs over every split k in (i, j): dp[i][k] + dp[k+1][j].  Span-ordered,
+// one barrier per span, a thread per cell; the traceback pushes (i,k) and (k+1,j) for code k-i+3.
+__global__ __launch_bounds__(DD_THREADS) void k_nussinov_dense(uint32_t L, const float* p, const float* q, float w, float th,
+                                                               float* dp, uint32_t* tr, uint32_t* stack, uint32_t* ss, float* score) {
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  for (size_t c = tid; c < (size_t)L * L; c += nt) { dp[c] = 0.0f; tr[c] = 0; }
+  for (uint32_t i = tid; i < L; i += nt) ss[i] = DD_NONE;
+  __syncthreads();
+  for (uint32_t l = 1; l < L; ++l) {
+    for (uint32_t i = tid; i + l < L; i += nt) {
+      const uint32_t j = i + l;
+      float v = 0.0f;
+      uint32_t t = 0;
+      if (i + 1 < j) { v = dp[(size_t)(i + 1) * L + j]; t = 1; }
+      if (i < j - 1 && v < dp[(size_t)i * L + j - 1]) { v = dp[(size_t)i * L + j - 1]; t = 2; }
+      const float pij = p[(size_t)i * L + j];
+      const float sm = q ? w * (pij - th) - q[(size_t)i * L + j] : pij - th;
+      if (i + 1 < j - 1) {
+        const float c = dp[(size_t)(i + 1) * L + j - 1] + sm;
+        if (v < c) { v = c; t = 3; }
+      }
+      for (uint32_t k = i + 1; k < j; ++k) {
+        const float c = dp[(size_t)i * L + k] + dp[(size_t)(k + 1) * L + j];
+        if (v < c) { v = c; t = k - i + 3; }
+      }
+      dp[(size_t)i * L + j] = v;
+      tr[(size_t)i * L + j] = t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    uint32_t sp = 0;
+    stack[0] = 0; stack[1] = L - 1; sp = 1;
+    uint32_t guard = 4 * L + 8;
+    while (sp && guard--) {
+      --sp;
+      const int i = (int)stack[2 * sp], j = (int)stack[2 * sp + 1];
+      const uint32_t t = tr[(size_t)i * L + j];
+      if (t == 0) continue;
+      if (t == 1) { stack[2 * sp] = i + 1; stack[2 * sp + 1] = j; ++sp; }
+      else if (t == 2) { stack[2 * sp] = i; stack[2 * sp + 1] = j - 1; ++sp; }
+      else if (t == 3) { ss[i] = j; stack[2 * sp] = i + 1; stack[2 * sp + 1] = j - 1; ++sp; }
+      else {
+        const int k = i + (int)t - 3;
+        stack[2 * sp] = i; stack[2 * sp + 1] = k; ++sp;
+        stack[2 * sp] = k + 1; stack[2 * sp + 1] = j; ++sp;
+      }
+    }
+    *score = dp[L - 1];
+  }
+}
+
 __global__ __launch_bounds__(DD_THREADS) void k_nw_single(uint32_t L1, uint32_t L2, const float* p, const float* q, float th,
                                                           uint32_t* env, int compute_env, float* dp, uint8_t* tr, uint32_t* al,
                                                           float* score) {
@@ -1564,6 +1617,11 @@ int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size
 }
 int nussinov_launch(uint32_t L, const float* p, const float* q, float w, float th, nuss_ws ws, uint32_t* ss, float* score, hipStream_t st) {
   hipLaunchKernelGGL(k_nussinov_single, dim3(1), dim3(DD_THREADS), 0, st, L, p, q, w, th, ws, ss, score);
+  return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
+}
+int nussinov_dense_launch(uint32_t L, const float* p, const float* q, float w, float th, float* dp, uint32_t* tr, uint32_t* stack, uint32_t* ss,
+                          float* score, hipStream_t st) {
+  hipLaunchKernelGGL(k_nussinov_dense, dim3(1), dim3(DD_THREADS), 0, st, L, p, q, w, th, dp, tr, stack, ss, score);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 int nw_launch(uint32_t L1, uint32_t L2, const float* p, const float* q, float th, uint32_t* env, int compute_env,

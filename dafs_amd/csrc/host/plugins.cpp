@@ -143,6 +143,47 @@ void HipSparseNussinov::make_brackets(const VU& ss, std::string& str) const {
   str.assign(buf.data());
 }
 
+float HipNussinov::decode(float w, const VVF& p, const VVF& q, VU& ss) {
+  std::vector<float> fp, fq;
+  flatten(p, fp);
+  flatten(q, fq);
+  ss.assign(p.size(), -1u);
+  float score = 0;
+  HipContext::check(dafs_hip_nussinov_decode_dense(ctx_->get(), th_, w, (uint32_t)p.size(), fp.data(), fq.data(), ss.data(), &score));
+  return score;
+}
+float HipNussinov::decode(const VVF& p, VU& ss, std::string& str) {
+  std::vector<float> fp;
+  flatten(p, fp);
+  ss.assign(p.size(), -1u);
+  float score = 0;
+  HipContext::check(dafs_hip_nussinov_decode_dense(ctx_->get(), th_, 0.0f, (uint32_t)p.size(), fp.data(), nullptr, ss.data(), &score));
+  make_brackets(ss, str);
+  return score;
+}
+void HipNussinov::make_brackets(const VU& ss, std::string& str) const {
+  std::vector<char> buf(ss.size() + 1);
+  dafs_hip_make_brackets((uint32_t)ss.size(), ss.data(), buf.data());
+  str.assign(buf.data());
+}
+float HipNeedlemanWunsch::decode(const VVF& p, const VVF& q, VU& al) const {
+  std::vector<float> fp, fq;
+  flatten(p, fp);
+  flatten(q, fq);
+  al.assign(p.size(), -1u);
+  float score = 0;
+  HipContext::check(dafs_hip_nw_decode_dense(ctx_->get(), th_, (uint32_t)p.size(), (uint32_t)p[0].size(), fp.data(), fq.data(), al.data(), &score));
+  return score;
+}
+float HipNeedlemanWunsch::decode(const VVF& p, VU& al) const {
+  std::vector<float> fp;
+  flatten(p, fp);
+  al.assign(p.size(), -1u);
+  float score = 0;
+  HipContext::check(dafs_hip_nw_decode_dense(ctx_->get(), th_, (uint32_t)p.size(), (uint32_t)p[0].size(), fp.data(), nullptr, al.data(), &score));
+  return score;
+}
+
 void HipSparseNeedlemanWunsch::initialize(const VVF& p) {
   std::vector<float> fp;
   flatten(p, fp);

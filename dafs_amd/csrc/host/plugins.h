@@ -108,6 +108,31 @@ class HipSparseNussinov : public Fold::Decoder {
   float th_;
 };
 
+// the dense decoder classes of the reference (src/nussinov.h:25-35, src/needleman_wunsch.h:26-36)
+class HipNussinov : public Fold::Decoder {
+ public:
+  HipNussinov(std::shared_ptr<HipContext> ctx, float th) : ctx_(ctx), th_(th) {}
+  float decode(float w, const VVF& p, const VVF& q, VU& ss);
+  float decode(const VVF& p, VU& ss, std::string& str);
+  void make_brackets(const VU& ss, std::string& str) const;
+
+ private:
+  std::shared_ptr<HipContext> ctx_;
+  float th_;
+};
+
+class HipNeedlemanWunsch : public Align::Decoder {
+ public:
+  HipNeedlemanWunsch(std::shared_ptr<HipContext> ctx, float th) : ctx_(ctx), th_(th) {}
+  void initialize(const VVF&) {}
+  float decode(const VVF& p, const VVF& q, VU& al) const;
+  float decode(const VVF& p, VU& al) const;
+
+ private:
+  std::shared_ptr<HipContext> ctx_;
+  float th_;
+};
+
 class HipSparseNeedlemanWunsch : public Align::Decoder {
  public:
   HipSparseNeedlemanWunsch(std::shared_ptr<HipContext> ctx, float th) : ctx_(ctx), th_(th) {}

@@ -251,6 +251,13 @@ int dafs_hip_nussinov_decode(dafs_hip_ctx* ctx, float th, float w, uint32_t L, c
 int dafs_hip_nw_envelope(dafs_hip_ctx* ctx, float th, uint32_t L1, uint32_t L2, const float* p, uint32_t* env);
 int dafs_hip_nw_decode(dafs_hip_ctx* ctx, float th, uint32_t L1, uint32_t L2, const float* p, const float* q,
                        const uint32_t* env, uint32_t* al, float* score);
+/* The dense decoder classes of the reference (Nussinov, src/nussinov.cpp:32-204: every pair scores, bifurcation over
+ * every split; NeedlemanWunsch, src/needleman_wunsch.cpp:28-196: no envelope).  DAFS instantiates the sparse ones
+ * (src/dafs.cpp:1692,1759); these complete the plugin set.  q may be NULL (the final-decode overloads). */
+int dafs_hip_nussinov_decode_dense(dafs_hip_ctx* ctx, float th, float w, uint32_t L, const float* p, const float* q,
+                                   uint32_t* ss, float* score);
+int dafs_hip_nw_decode_dense(dafs_hip_ctx* ctx, float th, uint32_t L1, uint32_t L2, const float* p, const float* q,
+                             uint32_t* al, float* score);
 /* make_brackets (src/nussinov.cpp:401-413): str needs L+1 bytes. Host-only helper. */
 void dafs_hip_make_brackets(uint32_t L, const uint32_t* ss, char* str);
 

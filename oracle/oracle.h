@@ -54,6 +54,9 @@ int orc_fold_calculate(const char* seq, uint32_t L, const char* constraint, floa
 float orc_nussinov_decode(float th, float w, uint32_t L, const float* p, const float* q, uint32_t* ss);
 void orc_make_brackets(uint32_t L, const uint32_t* ss, char* str /* L+1 */);
 /* SparseNeedlemanWunsch::initialize src/needleman_wunsch.cpp:198-253; env[2*(L1+1)] = first,second */
+/* dense classes Nussinov / NeedlemanWunsch (src/nussinov.cpp:32-204, src/needleman_wunsch.cpp:28-196); q may be NULL */
+float orc_nussinov_dense_decode(float th, float w, uint32_t L, const float* p, const float* q, uint32_t* ss);
+float orc_nw_dense_decode(float th, uint32_t L1, uint32_t L2, const float* p, const float* q, uint32_t* al);
 void orc_nw_envelope(float th, uint32_t L1, uint32_t L2, const float* p, uint32_t* env);
 /* SparseNeedlemanWunsch::decode :255-422; q may be NULL */
 float orc_nw_decode(float th, uint32_t L1, uint32_t L2, const float* p, const float* q,

@@ -13,6 +13,9 @@
 //   CONTRAFOLD::CONTRAfold<float>::ComputePosterior    src/contrafold/wrapper.cpp:181-200
 //   SparseNussinov::decode (both overloads)            src/nussinov.cpp:207-392
 //   SparseNeedlemanWunsch::initialize/decode           src/needleman_wunsch.cpp:198-422
+//   Nussinov::decode (both overloads, dense)           src/nussinov.cpp:32-204
+//   NeedlemanWunsch::decode (both overloads, dense)    src/needleman_wunsch.cpp:28-196
+//   AUXAlign::calculate (--align-aux reader)           src/align.cpp:204-246
 //   Fasta::load                                        src/fa.cpp:37-87
 //
 // src/fold.cpp cannot be compiled here (it includes ViennaRNA headers, absent from this
@@ -121,6 +124,61 @@ float ref_nw_decode(float th, uint32_t L1, uint32_t L2, const float* p, const fl
   float r = q ? d.decode(P, to_vvf(q, L1, L2), a) : d.decode(P, a);
   std::memcpy(al, a.data(), L1 * sizeof(uint32_t));
   return r;
+}
+
+// Nussinov::decode(w,p,q,ss) / decode(p,ss,str): the dense decoder (nussinov.cpp:32-204); q may be NULL (final overload)
+float ref_nussinov_dense_decode(float th, float w, uint32_t L, const float* p, const float* q, uint32_t* ss) {
+  Nussinov d(th);
+  VU s;
+  float r;
+  if (q) r = d.decode(w, to_vvf(p, L, L), to_vvf(q, L, L), s);
+  else { std::string b; r = d.decode(to_vvf(p, L, L), s, b); }
+  std::memcpy(ss, s.data(), L * sizeof(uint32_t));
+  return r;
+}
+
+// NeedlemanWunsch::decode (needleman_wunsch.cpp:28-196); q may be NULL
+float ref_nw_dense_decode(float th, uint32_t L1, uint32_t L2, const float* p, const float* q, uint32_t* al) {
+  NeedlemanWunsch d(th);
+  VVF P = to_vvf(p, L1, L2);
+  d.initialize(P);
+  VU a;
+  float r = q ? d.decode(P, to_vvf(q, L1, L2), a) : d.decode(P, a);
+  std::memcpy(al, a.data(), L1 * sizeof(uint32_t));
+  return r;
+}
+
+// AUXAlign::calculate(fa, mp) (align.cpp:204-246): the reference's own reader of the --align-aux format.
+// seqs: nseq strings (only their lengths matter to the reader).  Output, for every pair x < y in row-major order:
+// nnz[p], then len_x+1 row pointers (relative to the pair), then the entries -- the layout of dafs_hip_set_mp.
+// Returns the total number of entries, or -1 when a capacity is too small.
+long ref_auxalign_load(const char* file, int nseq, const char* const* seqs, uint32_t* nnz, uint32_t* rowptr, size_t rp_cap,
+                       uint32_t* col, float* val, size_t ent_cap) {
+  std::vector<Fasta> fa;
+  for (int i = 0; i < nseq; ++i) fa.push_back(Fasta("s", seqs[i]));
+  AUXAlign m(file, 0.0f);
+  std::vector<std::vector<MP> > mp;
+  m.calculate(fa, mp);
+  size_t rp = 0, e = 0, pidx = 0;
+  for (int x = 0; x < nseq; ++x)
+    for (int y = x + 1; y < nseq; ++y, ++pidx) {
+      const MP& m2 = mp[x][y];
+      const size_t L1 = fa[x].size();
+      if (rp + L1 + 1 > rp_cap) return -1;
+      uint32_t n = 0;
+      for (size_t i = 0; i < L1; ++i) {
+        rowptr[rp + i] = n;
+        if (i < m2.size())
+          for (auto& en : m2[i]) {
+            if (e >= ent_cap) return -1;
+            col[e] = en.first; val[e] = en.second; ++e; ++n;
+          }
+      }
+      rowptr[rp + L1] = n;
+      nnz[pidx] = n;
+      rp += L1 + 1;
+    }
+  return (long)e;
 }
 
 // Fasta::load (fa.cpp:37-87): returns count; names/seqs concatenated with '\n' separators.

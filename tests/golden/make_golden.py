@@ -89,6 +89,30 @@ def main():
             k += 1
     np.savez_compressed(os.path.join(HERE, "decoders.npz"), n=np.int64(k), **cases)
 
+    # the dense decoder classes (Nussinov, NeedlemanWunsch): same recipe, smaller sizes (the bifurcation loop is cubic)
+    rng = np.random.default_rng(2025)
+    cases = {}
+    k = 0
+    for L, L2 in ((1, 1), (2, 3), (4, 5), (17, 23), (60, 52), (96, 101)):
+        for dens in (0.0, 0.08, 0.4):
+            p = (rng.random((L, L)) * (rng.random((L, L)) < dens)).astype(np.float32)
+            q = ((rng.random((L, L)) - 0.3) * (rng.random((L, L)) < 0.3)).astype(np.float32)
+            if k % 2:
+                p = (np.round(p * 4) / 4).astype(np.float32)  # ties
+            w, th = np.float32([4.0, 2.6666667, 1.0][k % 3]), np.float32([0.2, 0.01, 0.5][k % 3])
+            s, ss = ref.nussinov_dense(p, q, th, w)
+            s2, ss2 = ref.nussinov_dense(p, None, th)
+            pz = (rng.random((L, L2)) * (rng.random((L, L2)) < max(dens, 0.02))).astype(np.float32)
+            qz = (rng.random((L, L2)) * (rng.random((L, L2)) < 0.3)).astype(np.float32)
+            tha = np.float32([0.01, 0.2][k % 2])
+            sz, al = ref.nw_dense(pz, qz, tha)
+            sz2, al2 = ref.nw_dense(pz, None, tha)
+            cases.update({"p%d" % k: p, "q%d" % k: q, "w%d" % k: w, "th%d" % k: th, "s%d" % k: s, "ss%d" % k: ss,
+                          "sf%d" % k: s2, "ssf%d" % k: ss2, "pz%d" % k: pz, "qz%d" % k: qz, "tha%d" % k: tha,
+                          "sz%d" % k: sz, "al%d" % k: al, "szf%d" % k: sz2, "alf%d" % k: al2})
+            k += 1
+    np.savez_compressed(os.path.join(HERE, "decoders_dense.npz"), n=np.int64(k), **cases)
+
     with open(os.path.join(HERE, "synth_checksums.txt"), "w") as f:
         for n, L, seed in ((32, 80, 12345), (128, 150, 12345), (256, 200, 12345), (512, 400, 12345)):
             f.write("random %d %d %d %s\n" % (n, L, seed, synth.checksum(synth.random_set(n, L, seed=seed, jitter=0.0 if L == 80 else 0.07))))

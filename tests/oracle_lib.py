@@ -105,6 +105,25 @@ class Oracle:
         s = self.lib.orc_nussinov_decode(th, w, L, p.ctypes.data, None if qp is None else qp.ctypes.data, ss.ctypes.data)
         return np.float32(s), ss
 
+    def nussinov_dense(self, p, q, th, w=0.0):
+        p = np.ascontiguousarray(p, np.float32)
+        L = p.shape[0]
+        ss = np.zeros(L, np.uint32)
+        qp = None if q is None else np.ascontiguousarray(q, np.float32)
+        self.lib.orc_nussinov_dense_decode.restype = C.c_float
+        self.lib.orc_nussinov_dense_decode.argtypes = [C.c_float, C.c_float, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+        s = self.lib.orc_nussinov_dense_decode(th, w, L, p.ctypes.data, None if qp is None else qp.ctypes.data, ss.ctypes.data)
+        return np.float32(s), ss
+
+    def nw_dense(self, p, q, th):
+        p = np.ascontiguousarray(p, np.float32)
+        al = np.zeros(p.shape[0], np.uint32)
+        qp = None if q is None else np.ascontiguousarray(q, np.float32)
+        self.lib.orc_nw_dense_decode.restype = C.c_float
+        self.lib.orc_nw_dense_decode.argtypes = [C.c_float, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+        s = self.lib.orc_nw_dense_decode(th, p.shape[0], p.shape[1], p.ctypes.data, None if qp is None else qp.ctypes.data, al.ctypes.data)
+        return np.float32(s), al
+
     def nw_envelope(self, p, th):
         p = np.ascontiguousarray(p, np.float32)
         env = np.zeros(2 * (p.shape[0] + 1), np.uint32)
@@ -268,6 +287,41 @@ class Ref:
         qp = None if q is None else np.ascontiguousarray(q, np.float32)
         s = self.lib.ref_nw_decode(th, p.shape[0], p.shape[1], p.ctypes.data, None if qp is None else qp.ctypes.data, al.ctypes.data)
         return np.float32(s), al
+
+    def nussinov_dense(self, p, q, th, w=0.0):
+        p = np.ascontiguousarray(p, np.float32); L = p.shape[0]
+        ss = np.zeros(L, np.uint32)
+        qp = None if q is None else np.ascontiguousarray(q, np.float32)
+        self.lib.ref_nussinov_dense_decode.restype = C.c_float
+        self.lib.ref_nussinov_dense_decode.argtypes = [C.c_float, C.c_float, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+        s = self.lib.ref_nussinov_dense_decode(th, w, L, p.ctypes.data, None if qp is None else qp.ctypes.data, ss.ctypes.data)
+        return np.float32(s), ss
+
+    def nw_dense(self, p, q, th):
+        p = np.ascontiguousarray(p, np.float32)
+        al = np.zeros(p.shape[0], np.uint32)
+        qp = None if q is None else np.ascontiguousarray(q, np.float32)
+        self.lib.ref_nw_dense_decode.restype = C.c_float
+        self.lib.ref_nw_dense_decode.argtypes = [C.c_float, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+        s = self.lib.ref_nw_dense_decode(th, p.shape[0], p.shape[1], p.ctypes.data, None if qp is None else qp.ctypes.data, al.ctypes.data)
+        return np.float32(s), al
+
+    def auxalign_load(self, path, seqs):
+        """the reference's own --align-aux reader (AUXAlign::calculate, src/align.cpp:204-246): (nnz, rowptr, col, val) of
+        every pair x < y in row-major order, rows of mp[x][y] (the layout of Context.set_mp)"""
+        n = len(seqs)
+        arr = (C.c_char_p * n)(*[s.encode() for s in seqs])
+        npairs = n * (n - 1) // 2
+        lens = [len(s) for s in seqs]
+        rp_cap = sum(lens[x] + 1 for x in range(n) for _ in range(x + 1, n))
+        ent_cap = sum(lens[x] * lens[y] for x in range(n) for y in range(x + 1, n))
+        nnz = np.zeros(npairs, np.uint32); rowptr = np.zeros(rp_cap, np.uint32)
+        col = np.zeros(ent_cap, np.uint32); val = np.zeros(ent_cap, np.float32)
+        self.lib.ref_auxalign_load.restype = C.c_long
+        self.lib.ref_auxalign_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+        e = self.lib.ref_auxalign_load(path.encode(), n, arr, nnz.ctypes.data, rowptr.ctypes.data, rp_cap, col.ctypes.data, val.ctypes.data, ent_cap)
+        assert e >= 0
+        return nnz, rowptr, col[:e], val[:e]
 
     def fasta(self, path):
         nb = C.create_string_buffer(1 << 20); sb = C.create_string_buffer(1 << 22)

@@ -100,6 +100,36 @@ def test_align_aux_round_trip(tmp_path):
     assert rc == 0 and out3 == out1, err
 
 
+def test_align_aux_file_read_by_the_reference_reader(ref, tmp_path):
+    """The wire format pinned from the other side: the file `dafs --save-align-aux` writes is parsed by the reference's
+    own AUXAlign::calculate (src/align.cpp:204-246, compiled into oracle/_ref), and what it loads equals the rows the
+    device computed, bit for bit (9 significant digits carry a float32 exactly)."""
+    from dafs_amd import capi
+    recs = synth.family_set(6, 55, seed=25) + synth.random_set(2, 40, seed=26)
+    seqs = [r[1] for r in recs]
+    fa = tmp_path / "f.fa"
+    fa.write_text(synth.to_fasta(recs))
+    for model, flag in ((capi.ALIGN_PROBCONS, "ProbCons"), (capi.ALIGN_CONTRALIGN, "CONTRAlign")):
+        aux = tmp_path / ("mp_%s.aux" % flag)
+        rc, out, err = run_cli("-a", flag, "--save-align-aux", str(aux), str(fa))
+        assert rc == 0, err
+        nnz, rowptr, col, val = ref.auxalign_load(str(aux), seqs)
+        ctx = capi.Context(0)
+        ctx.set_sequences(seqs)
+        dev = ctx.align_posteriors(model, 0.01)
+        ctx.close()
+        r0 = e0 = 0
+        for p in range(len(dev)):
+            rp, c, v = dev.csr(p)
+            l1 = len(seqs[int(dev.pair_x[p])])
+            assert nnz[p] == len(c), p
+            assert np.array_equal(rowptr[r0:r0 + l1 + 1], rp), p
+            assert np.array_equal(col[e0:e0 + len(c)], c) and val[e0:e0 + len(c)].tobytes() == v.tobytes(), p
+            r0 += l1 + 1
+            e0 += len(c)
+        assert e0 == len(col)
+
+
 def test_single_sequence_and_refinement(tmp_path):
     one = tmp_path / "one.fa"
     one.write_text(">only\nGGGAAACCCUUUAGGGCCC\n")

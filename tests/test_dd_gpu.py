@@ -227,3 +227,41 @@ def test_forced_iterations_equal_oracle(oracle):
         assert [int(x) for x in it] == [t_max] * (len(seqs) - 1)
         assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
         assert sorted(v[1] for v in got.dd_log.values()) == sorted(int(x) for x in vi)
+
+
+# ---- the dense decoder classes: Nussinov, NeedlemanWunsch ----
+def test_dense_decoders_golden(ctx):
+    """device rows straight against the reference-generated fixture (tests/golden/make_golden.py, oracle/_ref)"""
+    z = np.load(os.path.join(G, "decoders_dense.npz"))
+    for k in range(int(z["n"])):
+        p, q, w, th = z["p%d" % k], z["q%d" % k], float(z["w%d" % k]), float(z["th%d" % k])
+        s, ss = ctx.nussinov_dense(p, q, th, w)
+        assert np.float32(s).tobytes() == np.float32(z["s%d" % k]).tobytes() and np.array_equal(ss, z["ss%d" % k]), k
+        s, ss = ctx.nussinov_dense(p, None, th)
+        assert np.float32(s).tobytes() == np.float32(z["sf%d" % k]).tobytes() and np.array_equal(ss, z["ssf%d" % k]), k
+        pz, qz, tha = z["pz%d" % k], z["qz%d" % k], float(z["tha%d" % k])
+        s, al = ctx.nw_dense(pz, qz, tha)
+        assert np.float32(s).tobytes() == np.float32(z["sz%d" % k]).tobytes() and np.array_equal(al, z["al%d" % k]), k
+        s, al = ctx.nw_dense(pz, None, tha)
+        assert np.float32(s).tobytes() == np.float32(z["szf%d" % k]).tobytes() and np.array_equal(al, z["alf%d" % k]), k
+
+
+def test_dense_decoders_fuzz_vs_oracle(ctx, oracle):
+    rng = np.random.default_rng(78)
+    for t in range(20):
+        L = int(rng.choice([1, 2, 3, 5, 31, 70, 130]))
+        L2 = int(rng.choice([1, 2, 6, 40, 111]))
+        dens = float(rng.choice([0.0, 0.05, 0.5]))
+        p = (rng.random((L, L)) * (rng.random((L, L)) < dens)).astype(np.float32)
+        if t % 2:
+            p = (np.round(p * 4) / 4).astype(np.float32)
+        q = ((rng.random((L, L)) - 0.4) * (rng.random((L, L)) < 0.3)).astype(np.float32)
+        w, th = float(rng.choice([4.0, 1.3333334])), float(rng.choice([0.2, 0.05]))
+        for qq in (q, None):
+            a, b = ctx.nussinov_dense(p, qq, th, w), oracle.nussinov_dense(p, qq, th, w)
+            assert np.float32(a[0]).tobytes() == np.float32(b[0]).tobytes() and np.array_equal(a[1], b[1]), (t, L)
+        pz = (rng.random((L, L2)) * (rng.random((L, L2)) < max(dens, 0.02))).astype(np.float32)
+        qz = (rng.random((L, L2)) * (rng.random((L, L2)) < 0.2)).astype(np.float32)
+        for qq in (qz, None):
+            a, b = ctx.nw_dense(pz, qq, 0.01), oracle.nw_dense(pz, qq, 0.01)
+            assert np.float32(a[0]).tobytes() == np.float32(b[0]).tobytes() and np.array_equal(a[1], b[1]), (t, L, L2)

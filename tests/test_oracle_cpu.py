@@ -98,6 +98,38 @@ def test_decoders_golden(oracle):
         assert np.float32(s).tobytes() == np.float32(z["szf%d" % k]).tobytes() and np.array_equal(al, z["alf%d" % k])
 
 
+def test_dense_decoders_golden(oracle):
+    """the restatement of the dense classes (Nussinov, NeedlemanWunsch) against the reference-generated fixture"""
+    z = np.load(os.path.join(G, "decoders_dense.npz"))
+    for k in range(int(z["n"])):
+        p, q, w, th = z["p%d" % k], z["q%d" % k], float(z["w%d" % k]), float(z["th%d" % k])
+        s, ss = oracle.nussinov_dense(p, q, th, w)
+        assert np.float32(s).tobytes() == np.float32(z["s%d" % k]).tobytes() and np.array_equal(ss, z["ss%d" % k]), k
+        s, ss = oracle.nussinov_dense(p, None, th)
+        assert np.float32(s).tobytes() == np.float32(z["sf%d" % k]).tobytes() and np.array_equal(ss, z["ssf%d" % k]), k
+        pz, qz, tha = z["pz%d" % k], z["qz%d" % k], float(z["tha%d" % k])
+        s, al = oracle.nw_dense(pz, qz, tha)
+        assert np.float32(s).tobytes() == np.float32(z["sz%d" % k]).tobytes() and np.array_equal(al, z["al%d" % k]), k
+        s, al = oracle.nw_dense(pz, None, tha)
+        assert np.float32(s).tobytes() == np.float32(z["szf%d" % k]).tobytes() and np.array_equal(al, z["alf%d" % k]), k
+
+
+def test_dense_decoders_fuzz_vs_reference(oracle, ref):
+    rng = np.random.default_rng(5)
+    for t in range(12):
+        L, L2 = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+        p = (rng.random((L, L)) * (rng.random((L, L)) < 0.2)).astype(np.float32)
+        q = ((rng.random((L, L)) - 0.4) * (rng.random((L, L)) < 0.3)).astype(np.float32)
+        for qq in (q, None):
+            a, b = oracle.nussinov_dense(p, qq, 0.1, 3.0), ref.nussinov_dense(p, qq, 0.1, 3.0)
+            assert np.float32(a[0]).tobytes() == np.float32(b[0]).tobytes() and np.array_equal(a[1], b[1]), t
+        pz = (rng.random((L, L2)) * (rng.random((L, L2)) < 0.1)).astype(np.float32)
+        qz = (rng.random((L, L2)) * (rng.random((L, L2)) < 0.2)).astype(np.float32)
+        for qq in (qz, None):
+            a, b = oracle.nw_dense(pz, qq, 0.01), ref.nw_dense(pz, qq, 0.01)
+            assert np.float32(a[0]).tobytes() == np.float32(b[0]).tobytes() and np.array_equal(a[1], b[1]), t
+
+
 def _orc_fold_post(oracle, s, cons=None):
     L = len(s)
     out = np.zeros((L + 1) * (L + 2) // 2, np.float32)
