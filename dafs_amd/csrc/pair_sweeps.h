@@ -310,11 +310,12 @@ inline int pair_occupancy(int vgprs) {
 // (profiles/r02_b_variants.txt): a wavefront executes (max_len1 + G) steps, each worth step_cost + cell_cost * (W - 1/2)
 // ns of its SIMD's issue time (most waves of a batch run the W-1 instantiation); a SIMD that holds k wavefronts at
 // once works at eff(k) = 0.5 / 0.75 / 1 of its issue rate for k = 1 / 2 / 3 or more (the sweeps wait on LDS lookups
-// and on their slab); whole-wave groups spend 0.83 of that per step (no seam, uniform pair bounds); and when the
-// batch needs r > 1 rounds of resident wavefronts the rounds overlap each other's memory-bound and issue-bound
-// sweeps (x 1 - 0.17 (1 - 1/r)).  k comes from the code object's register count (hipFuncGetAttributes), not from a guess.
+// and on their slab); whole-wave groups spend whole_wave_factor of that per step (ProbCons 0.83: no seam, uniform
+// pair bounds; CONTRAlign 1); and when the batch needs r > 1 rounds of resident wavefronts the rounds overlap each
+// other's memory-bound and issue-bound sweeps (x 1 - round_overlap (1 - 1/r); ProbCons 0.17, CONTRAlign 0: its
+// 1.8 us per cell and wavefront hold for every variant measured).  k comes from the code object's register count (hipFuncGetAttributes), not from a guess.
 inline int pair_choose(pair_variant* vs, int nv, uint32_t ntasks, uint32_t max_len1, uint32_t max_len2, int planes,
-                       double step_cost, double cell_cost, dafs_pairhmm_plan* plan) {
+                       double step_cost, double cell_cost, double whole_wave_factor, double round_overlap, dafs_pairhmm_plan* plan) {
   int cus = 256, dev = 0;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;
@@ -345,9 +346,9 @@ inline int pair_choose(pair_variant* vs, int nv, uint32_t ntasks, uint32_t max_l
     const double n = (double)waves / (4.0 * cus);  // wavefronts per SIMD over the whole batch
     const double kres = n < 1.0 ? 1.0 : (n < occ ? n : (double)occ);  // resident at once
     const double eff = kres < 1.5 ? 0.5 : (kres < 2.5 ? 0.75 : 1.0);
-    const double step = (step_cost + cell_cost * (v.W - 0.5)) * (v.G == 64 ? 0.83 : 1.0);
+    const double step = (step_cost + cell_cost * (v.W - 0.5)) * (v.G == 64 ? whole_wave_factor : 1.0);
     const double rounds = n > occ ? n / occ : 1.0;
-    const double cost = (double)(max_len1 + v.G) * step * (n < 1.0 ? 1.0 : n) / eff * (1.0 - 0.17 * (1.0 - 1.0 / rounds));
+    const double cost = (double)(max_len1 + v.G) * step * (n < 1.0 ? 1.0 : n) / eff * (1.0 - round_overlap * (1.0 - 1.0 / rounds));
     if (!best || cost < best_cost) { best = &v; best_cost = cost; best_occ = occ; }
   }
   if (!best) return DAFS_HIP_ETOOLONG;

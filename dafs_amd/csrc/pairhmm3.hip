@@ -384,7 +384,7 @@ using namespace dafs;
 
 extern "C" int dafs_hipk_pairhmm_plan(uint32_t ntasks, uint32_t max_len1, uint32_t max_len2, dafs_pairhmm_plan* plan) {
   if (!plan || ntasks == 0 || max_len1 == 0 || max_len2 == 0) return DAFS_HIP_EINVAL;
-  return pair_choose(k_variants, k_nvariants, ntasks, max_len1, max_len2, 2, 600.0, 370.0, plan);  // two planes: slab + entry lists
+  return pair_choose(k_variants, k_nvariants, ntasks, max_len1, max_len2, 2, 600.0, 370.0, 0.83, 0.17, plan);  // two planes: slab + entry lists
 }
 
 extern "C" int dafs_hipk_pairhmm3_launch(const dafs_pairhmm3_args* args, const dafs_pairhmm_plan* plan, void* hip_stream) {

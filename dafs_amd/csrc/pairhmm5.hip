@@ -294,7 +294,7 @@ using namespace dafs;
 
 extern "C" int dafs_hipk_pairhmm5_plan(uint32_t ntasks, uint32_t max_len1, uint32_t max_len2, dafs_pairhmm_plan* plan) {
   if (!plan || ntasks == 0 || max_len1 == 0 || max_len2 == 0) return DAFS_HIP_EINVAL;
-  return pair_choose(k_variants5, k_nvariants5, ntasks, max_len1, max_len2, 5, 1200.0, 1400.0, plan);  // five planes
+  return pair_choose(k_variants5, k_nvariants5, ntasks, max_len1, max_len2, 5, 0.0, 1800.0, 1.0, 0.0, plan);  // five planes
 }
 
 extern "C" int dafs_hipk_pairhmm5_launch(const dafs_pairhmm5_args* args, const dafs_pairhmm_plan* plan, void* hip_stream) {
