@@ -207,6 +207,7 @@ dd_params device_params(const dafs_dd_params* prm) {
   dp.w = prm->w; dp.eta0 = prm->eta0; dp.th_a = prm->th_a; dp.th_s = prm->th_s; dp.t_max = prm->t_max; dp.force_iters = prm->force_iters;
   dp.stamps = getenv("DAFS_HIP_DD_STAMPS") ? 1 : 0;
   dp.skip_xy = prm->skip_uncoupled_folds ? 1 : 0;
+  dp.debug_lose_folders = getenv("DAFS_HIP_DD_LOSE_FOLDERS") ? 1 : 0;
   dp.slice = 0;
   return dp;
 }
@@ -385,7 +386,7 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
   }
   if ((rc = c->d_nodes.upload(nodes.data(), nnodes, c->stream))) return rc;
   if ((rc = dd_cbp_fill_launch(c->d_nodes.ptr, nnodes, force_wide ? 0 : max_len, dp, c->stream))) return rc;
-  for (uint32_t b = 0; b < nnodes; ++b) c->dd_open.push_back({nodes[b], lds[b], split_lds[b], false, {blk0[b], blk1[b]}, {blk0_bytes[b], blk1_bytes[b]}, false});
+  for (uint32_t b = 0; b < nnodes; ++b) c->dd_open.push_back({nodes[b], lds[b], split_lds[b], false, {blk0[b], blk1[b]}, {blk0_bytes[b], blk1_bytes[b]}, false, false});
   return DAFS_HIP_OK;
 }
 
@@ -410,10 +411,10 @@ int nodes_advance(dafs_hip_ctx* c, uint32_t n, const uint32_t* handles, dd_param
   bool split = false;
   // three workgroups per node, one per CU (their LDS does not leave room for a second): all of them must fit the device
   if (split_allowed && (int)(nodes.size() * 3) <= c->num_cus - 16)
-    for (size_t b = 0; b < nodes.size(); ++b) split = split || c->dd_open[handles[who[b]]].split_lds != 0;
+    for (size_t b = 0; b < nodes.size(); ++b) split = split || (c->dd_open[handles[who[b]]].split_lds != 0 && !c->dd_open[handles[who[b]]].no_split);
   for (size_t b = 0; b < nodes.size(); ++b) {
     const dafs_hip_ctx::dd_open_node& on = c->dd_open[handles[who[b]]];
-    if (split && on.split_lds) {
+    if (split && on.split_lds && !on.no_split) {
       nodes[b].split = 1;
       nodes[b].lds_flags &= (1u | 32u);  // the leader keeps the alignment DP only
       lds_max = std::max(lds_max, on.split_lds);
@@ -433,6 +434,7 @@ int nodes_advance(dafs_hip_ctx* c, uint32_t n, const uint32_t* handles, dd_param
   if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
   for (size_t b = 0; b < nodes.size(); ++b) {
     const bool done = paused[b] == 0;
+    if (paused[b] == 2) c->dd_open[handles[who[b]]].no_split = true;  // its folders were lost: from now on the one-workgroup form
     c->dd_open[handles[who[b]]].finished = done;
     if (finished) finished[who[b]] = done ? 1 : 0;
   }
@@ -533,7 +535,14 @@ extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs
   int rc = nodes_open(c, nnodes, in, dp);
   std::vector<uint32_t> handles(nnodes);
   for (uint32_t b = 0; b < nnodes; ++b) handles[b] = b;
-  if (!rc) rc = nodes_advance(c, nnodes, handles.data(), dp, 0, nullptr);
+  // one launch runs every node to its end -- unless a split node lost its folding workgroups and was parked for the
+  // one-workgroup form (k_dd_solve): then the unfinished nodes go round again
+  std::vector<uint8_t> fin(nnodes, 0);
+  for (int round = 0; !rc && round < 4; ++round) {
+    rc = nodes_advance(c, nnodes, handles.data(), dp, 0, fin.data());
+    if (std::all_of(fin.begin(), fin.end(), [](uint8_t f) { return f != 0; })) break;
+  }
+  if (!rc && !std::all_of(fin.begin(), fin.end(), [](uint8_t f) { return f != 0; })) rc = DAFS_HIP_ELAUNCH;
   for (uint32_t b = 0; b < nnodes && !rc; ++b) rc = nodes_result(c, b, &out[b], dp.stamps != 0);
   (void)hipStreamSynchronize(c->stream);
   c->dd_reset();

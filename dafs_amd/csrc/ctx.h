@@ -133,7 +133,8 @@ struct dafs_hip_ctx {
   std::vector<dd_chunk> dd_chunks;
   std::map<uint8_t*, size_t> dd_free_blocks;  // start -> bytes
   size_t dd_in_use = 0, dd_peak = 0;
-  struct dd_open_node { dafs::dd_node nd; size_t lds, split_lds; bool finished; uint8_t* blk[2]; size_t blk_bytes[2]; bool released; };
+  struct dd_open_node { dafs::dd_node nd; size_t lds, split_lds; bool finished; uint8_t* blk[2]; size_t blk_bytes[2]; bool released;
+                        bool no_split; };  // no_split: a launch lost this node's folding workgroups once (k_dd_solve), keep it on one workgroup
   std::vector<dd_open_node> dd_open;
   void dd_free(uint8_t* p, size_t bytes) {
     if (!p || !bytes) return;

@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
   const float w_y = prm.w * 2 * nd.n2 / (nd.n1 + nd.n2);  // :1092
   __shared__ uint32_t s_cnt[DD_THREADS];
   __shared__ uint32_t s_violated, s_npos;
-  __shared__ int s_stop, s_bad;
+  __shared__ int s_stop, s_bad, s_lost;  // s_lost: a folder of this split node did not answer in time
   __shared__ float s_eta;
   __shared__ float s_score[3];
   __shared__ uint32_t s_slowxy[2];       // this iteration's x / y folding is still to be done by the span-ordered form
@@ -1228,7 +1228,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
   const uint32_t t_first = resume ? nd.info[1] : 0;
   if (tid == 0) {
     if (resume) { c = nd.fstate[0]; eta = nd.fstate[1]; s_prev = nd.fstate[2]; }
-    s_eta = eta; s_bad = 0;
+    s_eta = eta; s_bad = 0; s_lost = 0;
   }
   // dynamic LDS: previous-row buffers and candidate counters of the three wave DPs, then whichever
   // traceback tables fit (nd.lds_flags, decided by the host): bit 0 alignment, bit 1 x, bit 2 y
@@ -1291,6 +1291,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
   // prm.skip_xy: a node without consensus base pairs has nothing that couples its three subproblems, and the
   // caller has said it consumes the alignment alone (DAFS::align_alignments, dafs.cpp:896-912): no folding DPs
   const bool fold_on = !(prm.skip_xy && ncbp == 0);
+  if (split && !fold_on && tid == 0) sync_store(&nd.sync[0], DD_SYNC_EXIT);  // nothing to fold: the two folding workgroups leave at once
   for (t = t_first; t != prm.t_max; ++t) {
     if (split && fold_on) {
       // every thread's multiplier updates are out (the barrier that ended the previous iteration, or the one
@@ -1356,15 +1357,25 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     }
     if (tid == 0) {
       s_violated = 0;
-      if (split && fold_on) {  // collect the two foldings (bounded wait; a folder that never answers fails the node)
-        uint32_t spins = 0;
-        while ((sync_load(&nd.sync[1]) != t + 1 || sync_load(&nd.sync[2]) != t + 1) && ++spins < DD_SPIN_LIMIT) __builtin_amdgcn_s_sleep(16);
-        if (spins >= DD_SPIN_LIMIT) s_bad = 1;
+      if (split && fold_on) {
+        // Collect the two foldings.  The wait is bounded in time (wall_clock64, 100 MHz), not in spins: split mode only
+        // works while the node's three workgroups are on the machine together, and a kernel on another stream, a second
+        // context or a masked device can keep the folders off it.  A folder that has not answered after two seconds is
+        // taken for lost: nothing of iteration t has been applied yet (the multiplier updates follow), so the node is
+        // parked at t like a node whose slice ran out, marked for the one-workgroup form, and the host relaunches it.
+        const unsigned long long t_wait = wall_clock64();
+        bool lost = prm.debug_lose_folders != 0;  // tests: take the recovery path without waiting
+        while (!lost && (sync_load(&nd.sync[1]) != t + 1 || sync_load(&nd.sync[2]) != t + 1)) {
+          __builtin_amdgcn_s_sleep(16);
+          if (wall_clock64() - t_wait > 200000000ull) lost = true;
+        }
+        if (lost) s_lost = 1;
         s_score[0] = __uint_as_float(nd.sync[3]);
         s_score[1] = __uint_as_float(nd.sync[4]);
       }
     }
     __syncthreads();
+    if (s_lost) { paused = true; break; }  // every thread sees it after the barrier; iteration t is redone by the relaunch
     {
       // Foldings whose register form gave up (more than DD_CAP candidates in a column) or does not exist for this
       // width: the span-ordered form of the standalone decoder, both at once, on all threads; and no further
@@ -1550,7 +1561,8 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     }
     if (prm.stamps)
       for (int k = 0; k < 6; ++k) nd.info[8 + k] = (resume ? nd.info[8 + k] : 0u) + (uint32_t)tk[k];
-    if (paused_out) paused_out[blockIdx.x] = paused ? 1u : 0u;  // one word per node of the launch: a single copy tells the host who is done
+    // one word per node of the launch: a single copy tells the host who is done; 2 = parked because its folders were lost
+    if (paused_out) paused_out[blockIdx.x] = paused ? (s_lost ? 2u : 1u) : 0u;
   }
 }
 

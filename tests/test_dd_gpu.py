@@ -265,3 +265,27 @@ def test_dense_decoders_fuzz_vs_oracle(ctx, oracle):
         for qq in (qz, None):
             a, b = ctx.nw_dense(pz, qq, 0.01), oracle.nw_dense(pz, qq, 0.01)
             assert np.float32(a[0]).tobytes() == np.float32(b[0]).tobytes() and np.array_equal(a[1], b[1]), (t, L, L2)
+
+
+@pytest.mark.parametrize("level_sync", [False, True])
+def test_lost_folders_are_recovered(level_sync):
+    """Split mode (a node's two folding DPs on workgroups of their own) depends on all three workgroups being on the
+    machine together.  DAFS_HIP_DD_LOSE_FOLDERS=1 makes every leader treat its folders as lost at its first collect:
+    the node must be parked untouched, relaunched in the one-workgroup form and end with the same result -- not fail."""
+    from dafs_amd import pipeline
+    recs = synth.family_set(6, 300, seed=51)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    want = pipeline.run(names, seqs, level_sync=level_sync, skip_uncoupled_folds=False)
+    assert max(max(d) for d in pipeline.run(names, seqs).dd_dims.values()) > 250   # wide enough for split mode
+    os.environ["DAFS_HIP_DD_LOSE_FOLDERS"] = "1"
+    try:
+        got = pipeline.run(names, seqs, level_sync=level_sync, skip_uncoupled_folds=False)
+    finally:
+        os.environ.pop("DAFS_HIP_DD_LOSE_FOLDERS", None)
+    assert got.output == want.output and got.dd_log == want.dd_log
+    os.environ["DAFS_HIP_DD_SPLIT"] = "0"
+    try:
+        nosplit = pipeline.run(names, seqs, level_sync=level_sync, skip_uncoupled_folds=False)
+    finally:
+        os.environ.pop("DAFS_HIP_DD_SPLIT", None)
+    assert nosplit.output == want.output and nosplit.dd_log == want.dd_log
