@@ -606,12 +606,9 @@ int contrafold_launch(const cf_batch& B, uint32_t nseq, uint32_t max_len, hipStr
   if (ints > budget) return DAFS_HIP_ETOOLONG;
   const int use_ring = ints + ring <= budget && !getenv("DAFS_HIP_CF_NORING");  // the env switch is a tuning aid
   const size_t lds = ints + (use_ring ? ring : 0);
-  static bool attr = false;
-  if (!attr) {
-    if (hip_check(hipFuncSetAttribute((const void*)k_contrafold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget))) return DAFS_HIP_ELAUNCH;
-    if (hip_check(hipFuncSetAttribute((const void*)k_contrafold_posterior, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget))) return DAFS_HIP_ELAUNCH;
-    attr = true;
-  }
+  static bool attr_a[16] = {false}, attr_b[16] = {false};
+  if (!lds_optin_once((const void*)k_contrafold, (int)budget, attr_a)) return DAFS_HIP_ELAUNCH;
+  if (!lds_optin_once((const void*)k_contrafold_posterior, (int)budget, attr_b)) return DAFS_HIP_ELAUNCH;
   int fold_threads = CF_FOLD_THREADS;
   if (const char* e = getenv("DAFS_HIP_CF_THREADS")) {  // tuning aid: 64..1024 in whole wavefronts
     const int v = atoi(e);

@@ -599,11 +599,8 @@ int pct_match_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint32_
   const size_t lds = pct_rows_lds_bytes(a.in.nseq, row_cap);
   if (lds > kPctLdsBytes) return DAFS_HIP_ETOOLONG;
   a.max_len = max_len;
-  static bool attr = false;
-  if (!attr) {
-    if (hip_check(hipFuncSetAttribute((const void*)k_pct_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPctLdsBytes))) return DAFS_HIP_ELAUNCH;
-    attr = true;
-  }
+  static bool attr[16] = {false};
+  if (!lds_optin_once((const void*)k_pct_rows, (int)kPctLdsBytes, attr)) return DAFS_HIP_ELAUNCH;
   hipLaunchKernelGGL(k_pct_rows, dim3(count, (max_len + PCT_ROWS_PER_WG - 1) / PCT_ROWS_PER_WG), dim3(256), lds, st, a, pair0, row_cap);
   if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
   hipLaunchKernelGGL(k_pct_emit, dim3(count), dim3(256), (size_t)2 * (max_len + 2) * 4, st, a, pair0);
@@ -619,11 +616,8 @@ int pct_bp_launch(pct_bp_args a, uint32_t max_len, hipStream_t st) {
   const size_t lds = pct_rows_lds_bytes(a.mp.nseq, row_cap);
   if (lds > kPctLdsBytes) return DAFS_HIP_ETOOLONG;
   a.max_len = max_len;
-  static bool attr = false;
-  if (!attr) {
-    if (hip_check(hipFuncSetAttribute((const void*)k_pct_bp_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPctLdsBytes))) return DAFS_HIP_ELAUNCH;
-    attr = true;
-  }
+  static bool attr[16] = {false};
+  if (!lds_optin_once((const void*)k_pct_bp_rows, (int)kPctLdsBytes, attr)) return DAFS_HIP_ELAUNCH;
   hipLaunchKernelGGL(k_pct_bp_rows, dim3(a.mp.nseq, (max_len + PCT_ROWS_PER_WG - 1) / PCT_ROWS_PER_WG), dim3(256), lds, st, a, row_cap);
   if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
   hipLaunchKernelGGL(k_pct_bp_emit, dim3(a.mp.nseq), dim3(256), (size_t)(max_len + 2) * 4, st, a);
