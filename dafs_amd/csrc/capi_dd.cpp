@@ -299,7 +299,13 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
         auto wide_ok = [](uint32_t L, uint32_t cols) { return dd_fold_cols(L) <= cols; };  // a register form exists for this width
         size_t used = base_z;
         nd.lds_flags = lean;
+        // span form of both foldings side by side (whole dp triangles on chip: up to ~170 + 170 columns); DAFS_HIP_DD_SPAN=0
+        // keeps the column-owning forms (tests run both)
+        const char* span_env = getenv("DAFS_HIP_DD_SPAN");
+        const bool span_allowed = !(span_env && atoi(span_env) == 0);
+        const size_t span_xy = ((size_t)dd_span_words(L1) + dd_span_words(L2)) * 4 + 16;
         if (force_wide) {}
+        else if (span_allowed && nd.s_x && nd.s_y && L1 <= DD_SPAN_LMAX && L2 <= DD_SPAN_LMAX && used + span_xy + need_z <= kDdLdsBudget) { used += span_xy; nd.lds_flags |= 64u; }  // only with the alignment traceback on chip too
         else if (used + fast(L1) + fast(L2) <= kDdLdsBudget) { used += fast(L1) + fast(L2); nd.lds_flags |= 2u | 4u; }  // x and y side by side
         else if (wide_ok(L1, DD_WREG) && wide_ok(L2, DD_WREG) && used + shared <= kDdLdsBudget) { used += shared; nd.lds_flags |= 8u; }      // one region, x then y
         else if (wide_ok(L1, DD_WFOLD) && wide_ok(L2, DD_WFOLD) && used + shared_g <= kDdLdsBudget) { used += shared_g; nd.lds_flags |= 8u | 16u; }  // the same, codes in HBM
@@ -310,7 +316,7 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
         // in one workgroup; the leader then keeps only the alignment DP (its LDS need is covered by `used`).
         nd.split = 0; nd.fold_fast = 0;
         split_lds[b] = 0;
-        if (!(nd.lds_flags & 2) && !force_wide) {
+        if (!(nd.lds_flags & (2u | 64u)) && !force_wide) {
           size_t worst = 0;
           const uint32_t Ls[2] = {L1, L2};
           for (int r = 0; r < 2; ++r) {
@@ -460,9 +466,9 @@ int nodes_result(dafs_hip_ctx* c, uint32_t handle, dafs_node_output* out, bool s
   memcpy(&score, at(nd.score), 4);
   memcpy(info, at(nd.info), sizeof info);
   if (stamps)
-    fprintf(stderr, "dd node L1=%u L2=%u n=%u+%u ncbp=%u iters=%u slow-xy=%u+%u | us: x-dp %.0f x-traceback %.0f wait %.0f cbp %.0f update %.0f tail %.0f\n", nd.L1,
+    fprintf(stderr, "dd node L1=%u L2=%u n=%u+%u ncbp=%u iters=%u slow-xy=%u+%u | us: x-dp %.0f x-traceback %.0f wait %.0f cbp %.0f update %.0f tail %.0f | y %.0f z %.0f flags %x\n", nd.L1,
             nd.L2, nd.n1, nd.n2, info[0], info[1], info[4], info[5], info[8] / 100.0, info[9] / 100.0, info[10] / 100.0, info[11] / 100.0, info[12] / 100.0,
-            info[13] / 100.0);
+            info[13] / 100.0, info[14] / 100.0, info[15] / 100.0, nd.lds_flags);
   out->score = score;
   out->ncbp = info[0];
   out->iterations = info[1];

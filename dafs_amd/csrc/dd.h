@@ -31,7 +31,8 @@ struct dd_node {
                             // folding has no register form (more than DD_WFOLD columns per lane)
   float *pz_s, *qz_s;       // (L1+63)*ceil((L2+1)/64)*64 each: p_z, q_z in sweep order of the alignment DP
   uint32_t lds_flags;       // LDS plan: bit 0 packed alignment traceback, bit 1 / bit 2 fast form of the x / y folding DP, bit 3 / 4 shared region / codes in HBM,
-                            // bit 5 alignment wave DP without input row buffers (second alignment too long for them)
+                            // bit 5 alignment wave DP without input row buffers (second alignment too long for them),
+                            // bit 6 span form of both folding DPs side by side (whole triangles in LDS; s_x / s_y are then stored by span)
   uint32_t* env;      // 2*(L1+1)
   // sparse structure of p_x / p_y / p_z (> CUTOFF) and of the consensus base pairs
   int32_t *xmap, *ymap, *zmap;    // dense cell -> entry id (px / py / cz lists) or -1
@@ -85,6 +86,12 @@ static inline __host__ __device__ uint32_t dd_ring_words(uint32_t L) {
   const uint32_t a = dd_ring_rows(L) * L, b = dd_slow_words(L);
   return a > b ? a : b;
 }
+// Span form of a folding DP (dd.hip, nuss_wave_span): packed codes, the whole dp triangle, DD_CAP candidate values and
+// row offsets for each of L + 1 columns (16-byte slots), DD_CAP split rows per column.  Each part starts on 16 bytes.
+#define DD_SPAN_LMAX 256  // four row slots per lane
+static inline __host__ __device__ uint32_t dd_span_nib_words(uint32_t L) { return (uint32_t)((((size_t)L * (L + 1) / 2 + 7) / 8 + 3) & ~(size_t)3); }
+static inline __host__ __device__ uint32_t dd_span_tri_words(uint32_t L) { return (uint32_t)(((size_t)L * (L + 1) / 2 + 3) & ~(size_t)3); }
+static inline __host__ __device__ uint32_t dd_span_words(uint32_t L) { return dd_span_nib_words(L) + dd_span_tri_words(L) + 2 * DD_CAP * (L + 1) + DD_CAP * L; }
 static const size_t kDdLdsBudget = 156 * 1024;  // dynamic LDS of k_dd_solve (the CU has 160 KB; ~2.2 KB is static)
 int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, bool split, uint32_t* d_paused, hipStream_t st);
 // standalone decoders on dense device matrices (one workgroup each)

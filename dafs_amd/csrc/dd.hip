@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/dafs_hip.h"
 #include "dd.h"
 #include "hip_util.h"
@@ -441,6 +442,171 @@ __device__ __forceinline__ float nuss_wave_fast(uint32_t W, uint32_t L, const fl
   return trb ? nuss_wave_fast_t<false>(W, L, S, trb, trbg, ring, lck, lane, ovf) : nuss_wave_fast_t<true>(W, L, S, trb, trbg, ring, lck, lane, ovf);
 }
 
+// ------------------------------------------------------------------------------------------
+// Span-ordered single-wavefront folding DP ("span form"), for foldings whose whole triangle fits LDS.
+// nuss_wave_reg gives every lane W columns and walks the rows: L + L/W steps of W cells, of which only the upper
+// triangle is work -- 600 cell slots per lane at L = 150.  Here the lanes own ROWS (lane t: rows t, t+64, ...: NS
+// slots) and time is the span d = j - i: L - 3 steps, and a slot is only visited while its row still has a cell
+// of that span -- 257 slots per lane at L = 150.  What a cell needs:
+//   dp[i+1][j]   (span d-1, row i+1)  the neighbour lane's value of the previous step: one DPP shift (lane 63 takes
+//                                     lane 0's next slot through readfirstlane and a select)
+//   dp[i][j-1]   (span d-1, row i)    this lane's own previous value
+//   dp[i+1][j-1] (span d-2, row i+1)  the shifted value of the step before
+//   dp[i][k-1] of the column's candidates: row i again -- a lane only ever reads dp rows it wrote itself, so the
+//                                     table (row-major packed triangle in LDS) needs no ordering between lanes
+//   the candidates of column j (values and row offsets, DD_CAP slots of 16 bytes each in LDS, empty = -inf): written
+//   by the lanes that met them at earlier spans, fetched for the NEXT step's column j+1 at the end of a step, after
+//   this step's insertions (the lane one row down may just have added to that very column).
+// Codes, split rows (lck) and the overflow rule are those of nuss_wave_reg, so nuss_traceback_fast serves both.
+// S is stored by span: S[d * Lp + i], Lp = L rounded up to 64 (fold_sidx).
+template <int NS>
+__device__ float nuss_wave_span(uint32_t L_, const float* S_, uint32_t* trb_, float* tri_, float* cval_, uint32_t* ckof_, uint32_t* lck_, int lane, bool* ovf_out) {
+  // wave-uniform values in scalar registers: the compiler cannot see that what came out of the node descriptor is uniform,
+  // and would mask every slot guard and address computation lane by lane
+  const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)L_);
+  DD_GLB const float* S = (DD_GLB const float*)S_;
+  DD_LDS uint32_t* trb = (DD_LDS uint32_t*)trb_;  // one nibble per cell of the upper triangle, zeroed by the caller
+  DD_LDS char* tri = (DD_LDS char*)tri_;          // dp, packed triangle by rows; spans 0..2 hold 0 (zeroed once per launch)
+  DD_LDS char* cval = (DD_LDS char*)cval_;        // [L+1][DD_CAP] candidate values, -inf = empty (reset by the caller)
+  DD_LDS char* ckof = (DD_LDS char*)ckof_;        // [L+1][DD_CAP] byte offset of dp[.][k-1] within a row
+  DD_LDS uint32_t* lck = (DD_LDS uint32_t*)lck_;  // [DD_CAP][L] split row of candidate x of column j (traceback)
+  static_assert(DD_CAP == 4, "the candidate slots are read as one 16-byte word");
+  typedef float v4f __attribute__((ext_vector_type(4)));        // builtin vectors: loadable through address-space-qualified pointers
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  const uint32_t Lp = (L + 63) & ~63u;
+  float prev[NS], dg[NS];
+  uint32_t qrow[NS], rb[NS];
+  v4f cv[NS];
+  v4u ck[NS];
+  // A step is a few hundred nanoseconds, a load from L2/HBM longer: the scores are fetched PF steps ahead into a
+  // rotating set of registers (the loop below is unrolled by PF so that the rotation is static).
+  constexpr int PF = 4;
+  float sq[PF][NS];
+  auto fetch = [&](uint32_t dd, float (&dst)[NS]) {
+    if (dd < L) {
+#pragma unroll
+      for (int r = 0; r < NS; ++r)
+        if (64u * r < L - dd) dst[r] = S[(size_t)dd * Lp + (uint32_t)lane + 64u * r];
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < NS; ++r) {
+    const uint32_t i = (uint32_t)lane + 64u * r;
+    const uint32_t ic = i < L ? i : 0u;
+    qrow[r] = (uint32_t)tri_index(L, ic, ic);
+    rb[r] = (qrow[r] - ic) * 4u;
+    prev[r] = 0.0f; dg[r] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PF; ++k) sq[k][r] = 0.0f;
+    const uint32_t jn = i + 3 < L ? i + 3 : L;  // entry L: the always-empty list
+    cv[r] = *(DD_LDS const v4f*)(cval + jn * 16u);
+    ck[r] = *(DD_LDS const v4u*)(ckof + jn * 16u);
+  }
+#pragma unroll
+  for (int k = 0; k < PF; ++k) fetch(3u + k, sq[k]);
+  bool ovf = false;
+  // One span.  NA = row slots that still have a cell of this span (compile time: the caller branches on the span once
+  // per step, a scalar branch, and the slots need no guards of their own).
+  auto step = [&](auto na_tag, uint32_t d, const float (&sc)[NS]) {
+    constexpr int NA = decltype(na_tag)::value;
+    const uint32_t ncell = L - d;  // rows 0 .. ncell-1 have a cell of this span
+    float dk[NA][DD_CAP], below[NA];
+#pragma unroll
+    for (int r = 0; r < NA; ++r) {
+      DD_LDS const char* row = tri + rb[r];
+      dk[r][0] = *(DD_LDS const float*)(row + ck[r].x);
+      dk[r][1] = *(DD_LDS const float*)(row + ck[r].y);
+      dk[r][2] = *(DD_LDS const float*)(row + ck[r].z);
+      dk[r][3] = *(DD_LDS const float*)(row + ck[r].w);
+    }
+#pragma unroll
+    for (int r = 0; r < NA; ++r) {
+      int b = __builtin_amdgcn_update_dpp(0, __float_as_int(prev[r]), 0x130, 0xf, 0xf, false);  // wave_shl:1: lane l takes lane l+1
+      if (r + 1 < NS) {  // read outside the select: inside it the read would run with lane 63 alone and return lane 63's value
+        const int first = __builtin_amdgcn_readfirstlane(__float_as_int(prev[r + 1 < NS ? r + 1 : r]));
+        b = lane == 63 ? first : b;
+      }
+      below[r] = __int_as_float(b);
+    }
+#pragma unroll
+    for (int r = 0; r < NA; ++r) {
+      const uint32_t i = (uint32_t)lane + 64u * r;
+      const bool valid = i < ncell;
+      const uint32_t j = i + d;
+      float v = below[r];                       // nussinov.cpp:226-233
+      uint32_t t = 1u;
+      const bool m2 = v < prev[r];
+      v = m2 ? prev[r] : v; t = m2 ? 2u : t;
+      const float s = sc[r];
+      const float cand = dg[r] + s;             // :236
+      const bool pos = s > 0.0f;
+      const bool m3 = pos && v < cand;
+      v = m3 ? cand : v; t = m3 ? 3u : t;
+      const float cvx[DD_CAP] = {cv[r].x, cv[r].y, cv[r].z, cv[r].w};
+#pragma unroll
+      for (int x = 0; x < DD_CAP; ++x) {        // bifurcations, oldest candidate first (:245-255)
+        const float cx = dk[r][x] + cvx[x];
+        const bool m = v < cx;
+        v = m ? cx : v; t = m ? (uint32_t)(4 + x) : t;
+      }
+      if (valid) {
+        const uint32_t q = qrow[r] + d;
+        *(DD_LDS float*)(tri + q * 4u) = v;
+        __hip_atomic_fetch_or(&trb[q >> 3], t << ((q & 7u) * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (valid && pos) {                       // a new candidate for column j (slots fill in order: count the occupied ones)
+        const uint32_t nc = (cvx[0] > -INFINITY ? 1u : 0u) + (cvx[1] > -INFINITY ? 1u : 0u) + (cvx[2] > -INFINITY ? 1u : 0u) + (cvx[3] > -INFINITY ? 1u : 0u);
+        if (nc < DD_CAP) {
+          *(DD_LDS float*)(cval + j * 16u + nc * 4u) = cand;
+          *(DD_LDS uint32_t*)(ckof + j * 16u + nc * 4u) = i ? (i - 1) * 4u : 0u;
+          lck[nc * L + j] = i;
+        } else ovf = true;
+      }
+      dg[r] = below[r];
+      prev[r] = v;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < NA; ++r) {  // the lists of the next step's columns (a slot on its last span reads the empty list)
+      const uint32_t jn = (uint32_t)lane + 64u * r + d + 1;
+      const uint32_t jc = jn < L ? jn : L;
+      cv[r] = *(DD_LDS const v4f*)(cval + jc * 16u);
+      ck[r] = *(DD_LDS const v4u*)(ckof + jc * 16u);
+    }
+  };
+  for (uint32_t d0 = 3; d0 < L; d0 += PF) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const uint32_t d = d0 + k;
+      if (d < L) {
+        float cur[NS];
+#pragma unroll
+        for (int r = 0; r < NS; ++r) cur[r] = sq[k][r];
+        fetch(d + PF, sq[k]);
+        const uint32_t ncell = L - d;
+        if (NS >= 4 && ncell > 192) step(std::integral_constant<int, (NS >= 4 ? 4 : NS)>(), d, cur);
+        else if (NS >= 3 && ncell > 128) step(std::integral_constant<int, (NS >= 3 ? 3 : NS)>(), d, cur);
+        else if (NS >= 2 && ncell > 64) step(std::integral_constant<int, (NS >= 2 ? 2 : NS)>(), d, cur);
+        else step(std::integral_constant<int, 1>(), d, cur);
+      }
+    }
+  }
+  *ovf_out = __any(ovf);
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(prev[0])));  // dp[0][L-1]: row 0, last span
+}
+
+__device__ __noinline__ float nuss_wave_span_t(uint32_t L, const float* S, uint32_t* trb, float* tri, float* cval, uint32_t* ckof, uint32_t* lck, int lane, bool* ovf) {
+  switch ((L + 63) / 64) {
+    case 1: return nuss_wave_span<1>(L, S, trb, tri, cval, ckof, lck, lane, ovf);
+    case 2: return nuss_wave_span<2>(L, S, trb, tri, cval, ckof, lck, lane, ovf);
+    case 3: return nuss_wave_span<3>(L, S, trb, tri, cval, ckof, lck, lane, ovf);
+    case 4: return nuss_wave_span<4>(L, S, trb, tri, cval, ckof, lck, lane, ovf);
+    default: break;
+  }
+  *ovf = true;  // the planner (capi_dd.cpp) grants the span form up to DD_SPAN_LMAX columns only
+  return 0.0f;
+}
+
 // Traceback of nuss_wave_reg's codes by the whole wavefront.  The walk itself is sequential, but it consists
 // of runs: stretches of code 1 (i+1), of code 2 (j-1) and stacks of code 3 (i+1, j-1).  The lanes read the
 // next 64 cells along the current direction at once and a ballot finds where the run ends, so a run costs
@@ -496,8 +662,49 @@ __device__ void nuss_traceback_fast(uint32_t L, uint32_t* trb_, const uint8_t* t
   }
 }
 
+// The walk over the two-bit table by the whole wavefront (cf. nuss_traceback_fast): it consists of runs -- stretches
+// of M (i-1, k-1), of X (i-1) and of Y (k-1).  The lanes read the next 64 cells along the current direction at once, a
+// ballot finds where the run ends, and the run's entries of `al` are written together: two LDS round trips per run
+// instead of one per cell and a store each.  Row 0 / column 0 are implicit (Y / X); (0,0) ends the walk.
+__device__ bool nw_traceback_wave(uint32_t L1, uint32_t L2, const uint32_t* tr_, uint32_t* al_, int lane) {
+  DD_LDS const uint32_t* tr = (DD_LDS const uint32_t*)tr_;
+  DD_GLB uint32_t* al = (DD_GLB uint32_t*)al_;
+  const uint32_t W = L2 + 1;
+  auto code = [&](int i, int k) -> uint32_t {  // 1 M, 2 X, 3 Y; 0 at (0,0), outside the grid and where the DP left no mark
+    if (i < 0 || k < 0 || (i == 0 && k == 0)) return 0u;
+    if (i == 0) return 3u;
+    if (k == 0) return 2u;
+    const uint32_t q = (uint32_t)i * W + (uint32_t)k;
+    return (tr[q >> 4] >> ((q & 15u) * 2)) & 3u;
+  };
+  int i = (int)L1, k = (int)L2;
+  uint32_t guard = L1 + L2 + 2;
+  while ((i > 0 || k > 0) && guard--) {
+    const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)code(i, k));
+    if (t == 1u) {         // (i,k), (i-1,k-1), ...: the run ends at the first cell whose code is not M
+      const unsigned long long m = __ballot(code(i - 1 - lane, k - 1 - lane) != 1u);
+      const int r = m ? (int)__ffsll((long long)m) - 1 : 63;  // cells of the run after the first (at most 64 cells a turn)
+      if (lane <= r) al[i - 1 - lane] = (uint32_t)(k - 1 - lane);
+      i -= 1 + r; k -= 1 + r;
+    } else if (t == 2u) {  // X run: rows i, i-1, ... of column k
+      const unsigned long long m = __ballot(code(i - 1 - lane, k) != 2u);
+      const int r = m ? (int)__ffsll((long long)m) - 1 : 63;
+      if (lane <= r) al[i - 1 - lane] = DD_NONE;
+      i -= 1 + r;
+    } else if (t == 3u) {  // Y run
+      const unsigned long long m = __ballot(code(i, k - 1 - lane) != 3u);
+      const int r = m ? (int)__ffsll((long long)m) - 1 : 63;
+      k -= 1 + r;
+    } else return false;
+  }
+  return i == 0 && k == 0;
+}
+
 template <int W, bool TRL>
-__device__ float nw_wave_reg(uint32_t L1, uint32_t L2, const float* ps_, const float* qs_, float th, const uint32_t* env_, uint8_t* tr_, int lane) {
+__device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const float* qs_, float th_, const uint32_t* env_, uint8_t* tr_, int lane) {
+  // wave-uniform values in scalar registers (see nuss_wave_span)
+  const uint32_t L1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L1_), L2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L2_);
+  const float th = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(th_)));
   DD_GLB const float* ps = (DD_GLB const float*)ps_;
   DD_GLB const float* qs = (DD_GLB const float*)qs_;
   DD_GLB const uint32_t* env = (DD_GLB const uint32_t*)env_;
@@ -507,7 +714,7 @@ __device__ float nw_wave_reg(uint32_t L1, uint32_t L2, const float* ps_, const f
   float P[W], Pc[W], Qc[W], np[W], nq[W];
 #pragma unroll
   for (int c = 0; c < W; ++c) { P[c] = 0.0f; Pc[c] = ps[(size_t)c * 64 + lane]; Qc[c] = qs[(size_t)c * 64 + lane]; np[c] = 0.0f; nq[c] = 0.0f; }
-  float last = 0.0f, leftprev = 0.0f, score = 0.0f;
+  float last = 0.0f, leftprev = 0.0f;
   const int nsteps = (int)L1 + (int)((L2 + W) / W) - 1;  // lanes beyond column L2 have nothing to do
   uint32_t ef = 1u, es = 0u;
   if (lane == 0) { ef = env[2]; es = env[3]; }  // row 1
@@ -545,7 +752,6 @@ __device__ float nw_wave_reg(uint32_t L1, uint32_t L2, const float* ps_, const f
             __hip_atomic_fetch_or(&tr_l[q >> 4], t << ((q & 15u) * 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           } else tr_g[(size_t)i * T + k] = t == 1 ? 'M' : (t == 2 ? 'X' : 'Y');
         } else v = -FLT_MAX;
-        if (i == (int)L1 && k == L2) score = v;
       }
       diag = up;
       P[c] = v;
@@ -557,6 +763,11 @@ __device__ float nw_wave_reg(uint32_t L1, uint32_t L2, const float* ps_, const f
 #pragma unroll
     for (int c = 0; c < W; ++c) { Pc[c] = np[c]; Qc[c] = nq[c]; }
   }
+  // dp[L1][L2]: what the lane that owns column L2 holds there after its last row (rows beyond L1 leave P untouched)
+  float score = 0.0f;
+#pragma unroll
+  for (int c = 0; c < W; ++c)
+    if ((uint32_t)c == L2 % (uint32_t)W) score = P[c];
   return __shfl(score, (int)(L2 / W));
 }
 
@@ -584,12 +795,17 @@ __device__ __forceinline__ size_t nw_skew(uint32_t W, uint32_t i, uint32_t k) { 
   const uint32_t lane = k / W, c = k - lane * W, step = i - 1 + lane;
   return ((size_t)step * W + c) * 64 + lane;
 }
+// where the score of cell (i, j), j >= i, lives: by span for the span form (nuss_wave_span), else in sweep order
+__device__ __forceinline__ size_t fold_sidx(bool span, uint32_t L, uint32_t W, uint32_t i, uint32_t j) {
+  return span ? (size_t)(j - i) * ((L + 63) & ~63u) + i : nuss_skew(L, W, i, j);
+}
 // all threads: S = w*(p-th)-q (nussinov.cpp:236); the association is the reference's
-__device__ void dd_fill_scores(uint32_t L, const float* __restrict__ p, const float* __restrict__ q, float w, float th, float* S) {
+__device__ void dd_fill_scores(bool span, uint32_t L, const float* __restrict__ p, const float* __restrict__ q, float w, float th, float* S) {
   const uint32_t W = dd_fold_cols(L);
   for (size_t c = threadIdx.x; c < (size_t)L * L; c += blockDim.x) {
     const uint32_t i = (uint32_t)(c / L), j = (uint32_t)(c - (size_t)i * L);
-    S[nuss_skew(L, W, i, j)] = j >= i + 3 ? w * (p[c] - th) - q[c] : 0.0f;  // a pair spans at least three (nussinov.cpp:236 is inside the span loop)
+    if (span && j < i) continue;  // the span layout holds the upper triangle only
+    S[fold_sidx(span, L, W, i, j)] = j >= i + 3 ? w * (p[c] - th) - q[c] : 0.0f;  // a pair spans at least three (nussinov.cpp:236 is inside the span loop)
   }
 }
 __device__ void dd_fill_nw(uint32_t L1, uint32_t L2, const float* __restrict__ p, const float* __restrict__ q, float* ps, float* qs) {
@@ -624,7 +840,7 @@ __device__ float nw_wave(uint32_t L1, uint32_t L2, const float* __restrict__ ps_
       Qb[c * 64 + lane] = qs[(size_t)c * 64 + lane];
     }
   }
-  float last = 0.0f, leftprev = 0.0f, score = 0.0f;
+  float last = 0.0f, leftprev = 0.0f;
   const int nsteps = (int)L1 + (int)((L2 + W) / W) - 1;  // lanes beyond column L2 have nothing to do
   uint32_t ef = 1u, es = 0u;
   if (lane == 0) { ef = env[2]; es = env[3]; }  // row 1
@@ -660,7 +876,6 @@ __device__ float nw_wave(uint32_t L1, uint32_t L2, const float* __restrict__ ps_
           if (v < left) { v = left; t = 'Y'; }
           tr[(size_t)i * T + k] = t;
         } else v = -FLT_MAX;
-        if (i == (int)L1 && k == L2) score = v;
       }
       diag = up;
       P[c * 64 + lane] = v;
@@ -679,6 +894,7 @@ __device__ float nw_wave(uint32_t L1, uint32_t L2, const float* __restrict__ ps_
       }
     }
   }
+  const float score = P[(L2 % W) * 64 + lane];  // dp[L1][L2] in the lane that owns column L2: rows beyond L1 leave P untouched
   return __shfl(score, (int)(L2 / W));
 }
 
@@ -1253,8 +1469,19 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
   uint32_t *trzp = nullptr, *trxp = nullptr, *tryp = nullptr;
   float *ringx = nullptr, *ringy = nullptr;
   uint32_t *lckx = nullptr, *lcky = nullptr;
+  // span form (bit 6): dp triangle, candidate values and row offsets of each folding
+  const bool spanxy = (nd.lds_flags & 64u) != 0;
+  float *trix = nullptr, *triy = nullptr, *cvx = nullptr, *cvy = nullptr;
+  uint32_t *ckx = nullptr, *cky = nullptr;
   {
     uint32_t* w = (uint32_t*)lds_tail;
+    if (spanxy) {
+      w = (uint32_t*)(((uintptr_t)w + 15) & ~(uintptr_t)15);  // 16-byte candidate slots
+      trxp = w; w += dd_span_nib_words(L1); trix = (float*)w; w += dd_span_tri_words(L1);
+      cvx = (float*)w; w += DD_CAP * (L1 + 1); ckx = w; w += DD_CAP * (L1 + 1); lckx = w; w += DD_CAP * L1;
+      tryp = w; w += dd_span_nib_words(L2); triy = (float*)w; w += dd_span_tri_words(L2);
+      cvy = (float*)w; w += DD_CAP * (L2 + 1); cky = w; w += DD_CAP * (L2 + 1); lcky = w; w += DD_CAP * L2;
+    }
     if (nd.lds_flags & 1) { trzp = w; w += nzw; }
     if (nd.lds_flags & 2) { trxp = w; w += nxw; ringx = (float*)w; w += dd_ring_words(L1); lckx = w; w += DD_CAP * L1; }
     if (nd.lds_flags & 4) { tryp = w; w += nyw; ringy = (float*)w; w += dd_ring_words(L2); lcky = w; w += DD_CAP * L2; }
@@ -1266,17 +1493,22 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     }
     if (fastx) Px = ringx;
     if (fasty) Py = ringy;
+    if (spanxy) { Px = cvx; Py = cvy; }  // traceback stacks: the candidate values are dead once the DP is through
   }
 
   const bool shared_xy = (nd.lds_flags & 8) != 0;
   __shared__ uint32_t s_x_done;  // iteration whose x folding (DP + traceback) has released the shared region
   if (tid == 0) s_x_done = 0xFFFFFFFFu;
   uint8_t* trz = nd.tr_z;
+  if (spanxy) {  // spans 0..2 of the dp triangles hold 0 and are never written
+    for (uint32_t e = tid; e < dd_span_tri_words(L1); e += nt) trix[e] = 0.0f;
+    for (uint32_t e = tid; e < dd_span_tri_words(L2); e += nt) triy[e] = 0.0f;
+  }
   if (!resume) {
     nw_init_tr(L1, L2, trz);
     // sweep-order inputs of the three DPs, built once; the multiplier updates below keep them current
-    if (nd.s_x) dd_fill_scores(L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_x);  // only foldings with a register form keep one
-    if (nd.s_y) dd_fill_scores(L2, nd.p_y, nd.q_y, w_y, prm.th_s, nd.s_y);
+    if (nd.s_x) dd_fill_scores(spanxy, L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_x);  // only foldings with a register form keep one
+    if (nd.s_y) dd_fill_scores(spanxy, L2, nd.p_y, nd.q_y, w_y, prm.th_s, nd.s_y);
     dd_fill_nw(L1, L2, nd.p_z, nd.q_z, nd.pz_s, nd.qz_s);
   }
   __syncthreads();
@@ -1284,6 +1516,8 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
 
   // optional phase timing (100 MHz ticks accumulated over the iterations into info[8..13]; tuning aid)
   unsigned long long tk[7] = {0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+  __shared__ unsigned long long s_tky, s_tkz;  // time of the y folding and of the alignment DP, by their own wavefronts
+  if (tid == 0) { s_tky = 0; s_tkz = 0; }
 #define DD_TICK(k) if (prm.stamps && tid == 0) { const unsigned long long now = wall_clock64(); tk[k] += now - t_prev; t_prev = now; }
   if (prm.stamps && tid == 0) t_prev = wall_clock64();
   uint32_t ran = 0;
@@ -1306,6 +1540,10 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     if (trzp) for (uint32_t e = tid; e < nzw; e += nt) trzp[e] = 0;
     if (trxp) for (uint32_t e = tid; e < nxw; e += nt) trxp[e] = 0;
     if (tryp && !shared_xy) for (uint32_t e = tid; e < nyw; e += nt) tryp[e] = 0;
+    if (spanxy) {  // empty candidate lists (entry L / L2 is the list that stays empty)
+      for (uint32_t e = tid; e < DD_CAP * (L1 + 1); e += nt) { cvx[e] = -INFINITY; ckx[e] = 0; }
+      for (uint32_t e = tid; e < DD_CAP * (L2 + 1); e += nt) { cvy[e] = -INFINITY; cky[e] = 0; }
+    }
     // the three subproblems (dafs.cpp:1091-1093) side by side, one wavefront each, DP then traceback
     __syncthreads();
     if (!fold_on) {
@@ -1315,7 +1553,8 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     } else if (wave == 0) {
       bool slow = true;
       float sc = 0.0f;
-      if (ringx && !gave_up_x && Wx <= DD_WFOLD) sc = nuss_wave_fast(Wx, L1, nd.s_x, trxp, nd.trb_x, ringx, lckx, lane, &slow);
+      if (spanxy && !gave_up_x) sc = nuss_wave_span_t(L1, nd.s_x, trxp, trix, cvx, ckx, lckx, lane, &slow);
+      else if (ringx && !gave_up_x && Wx <= DD_WFOLD) sc = nuss_wave_fast(Wx, L1, nd.s_x, trxp, nd.trb_x, ringx, lckx, lane, &slow);
       if (slow && lane == 0 && prm.stamps) nd.info[4] += 1;  // iterations that took the slower form
       if (lane == 0) { s_slowxy[0] = slow ? 1u : 0u; s_score[0] = sc; }  // slow: the span-ordered form below, by everybody
       DD_TICK(0);
@@ -1328,25 +1567,32 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     } else if (wave == 1) {
       bool slow = true;
       float sc = 0.0f;
+      const unsigned long long ty0 = prm.stamps ? wall_clock64() : 0ull;
       if (shared_xy) {
         while (__hip_atomic_load(&s_x_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t) __builtin_amdgcn_s_sleep(8);
         if (tryp) for (uint32_t e = (uint32_t)lane; e < nyw; e += 64) tryp[e] = 0;
         wave_lds_fence();
       }
-      if (ringy && !gave_up_y && Wy <= DD_WFOLD) sc = nuss_wave_fast(Wy, L2, nd.s_y, tryp, nd.trb_y, ringy, lcky, lane, &slow);
+      if (spanxy && !gave_up_y) sc = nuss_wave_span_t(L2, nd.s_y, tryp, triy, cvy, cky, lcky, lane, &slow);
+      else if (ringy && !gave_up_y && Wy <= DD_WFOLD) sc = nuss_wave_fast(Wy, L2, nd.s_y, tryp, nd.trb_y, ringy, lcky, lane, &slow);
       if (slow && lane == 0 && prm.stamps) nd.info[5] += 1;
       if (lane == 0) { s_slowxy[1] = slow ? 1u : 0u; s_score[1] = sc; }
       if (!slow) nuss_traceback_fast(L2, tryp, nd.trb_y, lcky, nd.y, (uint32_t*)Py, lane);
+      if (prm.stamps && lane == 0) s_tky += wall_clock64() - ty0;
     }
     if (wave == 2) {
       float sc;
+      const unsigned long long tz0 = prm.stamps ? wall_clock64() : 0ull;
       if (Wz <= DD_WREG && !nw_lean) sc = trzp ? nw_wave_fast<true>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, (uint8_t*)trzp, lane)
                                    : nw_wave_fast<false>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, trz, lane);
       else sc = nw_wave(L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, trz, Pz, Pbz, Qbz, lane);
+      bool ok = true;
+      if (trzp && Wz <= DD_WREG && !nw_lean) { wave_lds_fence(); ok = nw_traceback_wave(L1, L2, trzp, nd.z, lane); }  // by the whole wavefront
+      else if (lane == 0) ok = nw_traceback(L1, L2, trz, nd.z);
       if (lane == 0) {
         s_score[2] = sc;
-        const bool ok = (trzp && Wz <= DD_WREG && !nw_lean) ? nw_traceback_packed(L1, L2, trzp, nd.z) : nw_traceback(L1, L2, trz, nd.z);
         if (!ok) s_bad = 1;
+        if (prm.stamps) s_tkz += wall_clock64() - tz0;
       }
     }
     DD_TICK(0);
@@ -1451,7 +1697,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
           const size_t o = (size_t)i * L1 + j;
           const float qn = nd.q_x[o] - eta * (tc - 1);
           nd.q_x[o] = qn;
-          if (nd.s_x && j >= i + 3) nd.s_x[nuss_skew(L1, Wx, i, j)] = w_x * (nd.p_x[o] - prm.th_s) - qn;
+          if (nd.s_x && j >= i + 3) nd.s_x[fold_sidx(spanxy, L1, Wx, i, j)] = w_x * (nd.p_x[o] - prm.th_s) - qn;
         }
       }
       for (uint32_t e = nd.px_ptr[i]; e < nd.px_ptr[i + 1]; ++e) {
@@ -1463,7 +1709,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
           const size_t o = (size_t)i * L1 + jj;
           const float qn = nd.q_x[o] - eta * tc;
           nd.q_x[o] = qn;
-          if (nd.s_x && jj >= i + 3) nd.s_x[nuss_skew(L1, Wx, i, jj)] = w_x * (nd.p_x[o] - prm.th_s) - qn;  // shorter spans stay 0 (dd_fill_scores)
+          if (nd.s_x && jj >= i + 3) nd.s_x[fold_sidx(spanxy, L1, Wx, i, jj)] = w_x * (nd.p_x[o] - prm.th_s) - qn;  // shorter spans stay 0 (dd_fill_scores)
         }
       }
       const uint32_t kz = nd.z[i];
@@ -1498,7 +1744,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
           const size_t o = (size_t)k * L2 + l;
           const float qn = nd.q_y[o] - eta * (tc - 1);
           nd.q_y[o] = qn;
-          if (nd.s_y && l >= k + 3) nd.s_y[nuss_skew(L2, Wy, k, l)] = w_y * (nd.p_y[o] - prm.th_s) - qn;
+          if (nd.s_y && l >= k + 3) nd.s_y[fold_sidx(spanxy, L2, Wy, k, l)] = w_y * (nd.p_y[o] - prm.th_s) - qn;
         }
       }
       for (uint32_t e = nd.py_ptr[k]; e < nd.py_ptr[k + 1]; ++e) {
@@ -1510,7 +1756,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
           const size_t o = (size_t)k * L2 + ll;
           const float qn = nd.q_y[o] - eta * tc;
           nd.q_y[o] = qn;
-          if (nd.s_y && ll >= k + 3) nd.s_y[nuss_skew(L2, Wy, k, ll)] = w_y * (nd.p_y[o] - prm.th_s) - qn;
+          if (nd.s_y && ll >= k + 3) nd.s_y[fold_sidx(spanxy, L2, Wy, k, ll)] = w_y * (nd.p_y[o] - prm.th_s) - qn;
         }
       }
     }
@@ -1560,7 +1806,11 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
       nd.info[3] = s_bad ? 1u : 0u;
     }
     if (prm.stamps)
+    {
       for (int k = 0; k < 6; ++k) nd.info[8 + k] = (resume ? nd.info[8 + k] : 0u) + (uint32_t)tk[k];
+      nd.info[14] = (resume ? nd.info[14] : 0u) + (uint32_t)s_tky;
+      nd.info[15] = (resume ? nd.info[15] : 0u) + (uint32_t)s_tkz;
+    }
     // one word per node of the launch: a single copy tells the host who is done; 2 = parked because its folders were lost
     if (paused_out) paused_out[blockIdx.x] = paused ? (s_lost ? 2u : 1u) : 0u;
   }

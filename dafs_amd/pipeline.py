@@ -159,6 +159,7 @@ def _phase2(ctx, own, names, seqs, n, sim, score, left, right, t, w, eta0, t_max
     res.dd_log = {}
     res.dd_dims = {}  # node -> (columns of the left, of the right alignment); resident-node mode only
     res.levels = 0
+    res.rounds = []  # resident-node mode: (seconds, [(node, columns left, columns right), ...]) per round (diagnostics)
     if level_sync:
         while pending:
             ready = [i for i in pending if left[i] in aln and right[i] in aln]
@@ -181,7 +182,9 @@ def _phase2(ctx, own, names, seqs, n, sim, score, left, right, t, w, eta0, t_max
                     open_nodes[i] = (h, d[0], d[1])
                 pending = [i for i in pending if i not in ready]
             ids = sorted(open_nodes)
+            t_round = time.perf_counter()
             fin = ctx.nodes_advance([open_nodes[i][0] for i in ids], prm, slice_iters)
+            res.rounds.append((time.perf_counter() - t_round, [(i, open_nodes[i][1], open_nodes[i][2]) for i in ids]))
             for i, f in zip(ids, fin):
                 if not f:
                     continue
