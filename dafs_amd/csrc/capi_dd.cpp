@@ -278,8 +278,6 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
       nd.dp_z = cv.take<float>(T); nd.tr_z = cv.take<uint8_t>(T);
       nd.trb_x = cv.take<uint8_t>(XX / 2 + L1 + 16); nd.trb_y = cv.take<uint8_t>(YY / 2 + L2 + 16);
       // steps x columns per lane x 64 lanes; only for foldings that have a register form
-      nd.s_x = (dd_fold_cols(L1) <= DD_WFOLD && !force_wide) ? cv.take<float>(((size_t)L1 + 63) * dd_fold_cols(L1) * 64) : nullptr;
-      nd.s_y = (dd_fold_cols(L2) <= DD_WFOLD && !force_wide) ? cv.take<float>(((size_t)L2 + 63) * dd_fold_cols(L2) * 64) : nullptr;
       nd.pz_s = cv.take<float>(((size_t)L1 + 63) * ((L2 + 64) / 64) * 64); nd.qz_s = cv.take<float>(((size_t)L1 + 63) * ((L2 + 64) / 64) * 64);
       nd.trk_x = nd.wx.tr; nd.trk_y = nd.wy.tr;  // the L*L uint32 tables double as bifurcation codes
       {  // LDS plan (mirrors the carving at the top of k_dd_solve / dd_folder)
@@ -305,7 +303,7 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
         const bool span_allowed = !(span_env && atoi(span_env) == 0);
         const size_t span_xy = ((size_t)dd_span_words(L1) + dd_span_words(L2)) * 4 + 16;
         if (force_wide) {}
-        else if (span_allowed && nd.s_x && nd.s_y && L1 <= DD_SPAN_LMAX && L2 <= DD_SPAN_LMAX && used + span_xy + need_z <= kDdLdsBudget) { used += span_xy; nd.lds_flags |= 64u; }  // only with the alignment traceback on chip too
+        else if (span_allowed && L1 <= DD_SPAN_LMAX && L2 <= DD_SPAN_LMAX && used + span_xy + need_z <= kDdLdsBudget) { used += span_xy; nd.lds_flags |= 64u; }  // only with the alignment traceback on chip too
         else if (used + fast(L1) + fast(L2) <= kDdLdsBudget) { used += fast(L1) + fast(L2); nd.lds_flags |= 2u | 4u; }  // x and y side by side
         else if (wide_ok(L1, DD_WREG) && wide_ok(L2, DD_WREG) && used + shared <= kDdLdsBudget) { used += shared; nd.lds_flags |= 8u; }      // one region, x then y
         else if (wide_ok(L1, DD_WFOLD) && wide_ok(L2, DD_WFOLD) && used + shared_g <= kDdLdsBudget) { used += shared_g; nd.lds_flags |= 8u | 16u; }  // the same, codes in HBM
@@ -316,12 +314,17 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
         // in one workgroup; the leader then keeps only the alignment DP (its LDS need is covered by `used`).
         nd.split = 0; nd.fold_fast = 0;
         split_lds[b] = 0;
-        if (!(nd.lds_flags & (2u | 64u)) && !force_wide) {
+        // Nodes whose foldings cannot take the span form side by side, but can on a workgroup of their own, are worth
+        // splitting even when the column-owning forms fit side by side: the span form is about twice as fast.
+        const bool span_folders = span_allowed && !force_wide && !(nd.lds_flags & 64u) && L1 <= DD_SPAN_LMAX && L2 <= DD_SPAN_LMAX &&
+                                  (size_t)dd_span_words(std::max(L1, L2)) * 4 + 16 <= kDdLdsBudget;
+        if ((!(nd.lds_flags & (2u | 64u)) || span_folders) && !force_wide) {
           size_t worst = 0;
           const uint32_t Ls[2] = {L1, L2};
           for (int r = 0; r < 2; ++r) {
             const uint32_t L = Ls[r];
-            if (wide_ok(L, DD_WREG) && fast(L) <= kDdLdsBudget) { nd.fold_fast |= 1u << r; worst = std::max(worst, fast(L)); }
+            if (span_folders) { nd.fold_fast |= 16u << r; worst = std::max(worst, (size_t)dd_span_words(L) * 4 + 16); }
+            else if (wide_ok(L, DD_WREG) && fast(L) <= kDdLdsBudget) { nd.fold_fast |= 1u << r; worst = std::max(worst, fast(L)); }
             else if (wide_ok(L, DD_WFOLD) && fast_g(L) <= kDdLdsBudget) { nd.fold_fast |= 4u << r; worst = std::max(worst, fast_g(L)); }
             // else span-ordered on HBM tables: no LDS
           }
@@ -329,6 +332,16 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
           // whole workgroup, far ahead of the HBM-table wave form the leader would run for it
           if (nd.fold_fast || !wide_ok(L1, DD_WFOLD) || !wide_ok(L2, DD_WFOLD)) split_lds[b] = std::max(worst, used);
         }
+      }
+      // pair scores in the order the folding DPs read them: sweep order (steps x columns per lane x 64 lanes) for the
+      // column-owning forms unless no launch uses them, by span for the span form
+      {
+        const bool span_only = (nd.lds_flags & 64u) != 0;
+        const bool span_any = span_only || (nd.fold_fast & (16u | 32u)) != 0;
+        nd.s_x = (dd_fold_cols(L1) <= DD_WFOLD && !force_wide && !span_only) ? cv.take<float>(((size_t)L1 + 63) * dd_fold_cols(L1) * 64) : nullptr;
+        nd.s_y = (dd_fold_cols(L2) <= DD_WFOLD && !force_wide && !span_only) ? cv.take<float>(((size_t)L2 + 63) * dd_fold_cols(L2) * 64) : nullptr;
+        nd.s_xs = span_any ? cv.take<float>((size_t)L1 * ((L1 + 63) & ~63u) + 64) : nullptr;
+        nd.s_ys = span_any ? cv.take<float>((size_t)L2 * ((L2 + 63) & ~63u) + 64) : nullptr;
       }
       nd.env = cv.take<uint32_t>(2 * ((size_t)L1 + 1));
       nd.px_ptr = cv.take<uint32_t>((size_t)L1 + 2); nd.px_j = cv.take<uint32_t>(XX / 2 + 2);

@@ -29,10 +29,12 @@ struct dd_node {
   uint32_t *trk_x, *trk_y;  // L*L each: bifurcation code of the cells whose traceback code is 4
   float *s_x, *s_y;         // (L+63)*ceil(L/64)*64 each: pair scores w*(p-th)-q in sweep order of the folding DP; null when the
                             // folding has no register form (more than DD_WFOLD columns per lane)
+  float *s_xs, *s_ys;       // L*Lp each (Lp = L rounded up to 64): the same scores stored by span, S[(j-i)*Lp + i], for the span form
+                            // (nuss_wave_span); null when no launch of this node can take that form
   float *pz_s, *qz_s;       // (L1+63)*ceil((L2+1)/64)*64 each: p_z, q_z in sweep order of the alignment DP
   uint32_t lds_flags;       // LDS plan: bit 0 packed alignment traceback, bit 1 / bit 2 fast form of the x / y folding DP, bit 3 / 4 shared region / codes in HBM,
                             // bit 5 alignment wave DP without input row buffers (second alignment too long for them),
-                            // bit 6 span form of both folding DPs side by side (whole triangles in LDS; s_x / s_y are then stored by span)
+                            // bit 6 span form of both folding DPs side by side (whole triangles in LDS; scores from s_xs / s_ys)
   uint32_t* env;      // 2*(L1+1)
   // sparse structure of p_x / p_y / p_z (> CUTOFF) and of the consensus base pairs
   int32_t *xmap, *ymap, *zmap;    // dense cell -> entry id (px / py / cz lists) or -1
@@ -51,7 +53,8 @@ struct dd_node {
   float* fstate;                  // [4]: c, eta, previous dual value of a paused node
   // split mode: the two folding DPs of this node run on workgroups of their own (blockIdx.y = 1, 2) next to
   // the leader (blockIdx.y = 0, alignment DP + constraints + updates); sync[0] go / exit, [1] x done, [2] y done,
-  // [3] [4] the folding scores.  fold_fast: bit 0 / 1 the fast form of x / y fits the folder's LDS.
+  // [3] [4] the folding scores.  fold_fast: bit 0 / 1 the fast form of x / y fits the folder's LDS, bit 2 / 3 the same with the
+  // codes in HBM, bit 4 / 5 the span form fits it (preferred).
   uint32_t* sync;
   uint32_t split, fold_fast;
 };

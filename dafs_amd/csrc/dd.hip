@@ -1360,6 +1360,17 @@ __device__ __noinline__ void dd_folder(const dd_node& nd, const dd_params& prm, 
   uint32_t *trbp = nullptr, *lck = nullptr;
   float* ring = nullptr;
   float* P = (float*)s_dd;  // traceback stack of the register form: inside its ring, which is idle by then
+  // span form (fold_fast bit 4 / 5): codes, dp triangle, candidate values and row offsets, split rows -- as in k_dd_solve
+  const bool span = (nd.fold_fast & (isx ? 16u : 32u)) != 0;
+  float *tri = nullptr, *cvl = nullptr;
+  uint32_t* ckl = nullptr;
+  if (span) {
+    uint32_t* w = (uint32_t*)(((uintptr_t)s_dd + 15) & ~(uintptr_t)15);
+    trbp = w; w += dd_span_nib_words(L); tri = (float*)w; w += dd_span_tri_words(L);
+    cvl = (float*)w; w += DD_CAP * (L + 1); ckl = w; w += DD_CAP * (L + 1); lck = w;
+    P = cvl;  // traceback stack: the candidate values are dead once the DP is through
+    for (uint32_t e = tid; e < dd_span_tri_words(L); e += nt) tri[e] = 0.0f;  // spans 0..2 hold 0 and are never written
+  } else
   if (nd.fold_fast & (isx ? 1u : 2u)) { trbp = (uint32_t*)s_dd; ring = (float*)(trbp + nw); lck = (uint32_t*)(ring + dd_ring_words(L)); P = ring; }
   else if (nd.fold_fast & (isx ? 4u : 8u)) { ring = (float*)s_dd; lck = (uint32_t*)(ring + dd_ring_words(L)); P = ring; }  // codes in HBM
   for (uint32_t it = t_first;; ++it) {
@@ -1372,13 +1383,15 @@ __device__ __noinline__ void dd_folder(const dd_node& nd, const dd_params& prm, 
     if (!s_go) break;
     for (uint32_t i = tid; i < L; i += nt) ss[i] = DD_NONE;
     if (trbp) for (uint32_t e = tid; e < nw; e += nt) trbp[e] = 0;
+    if (span) for (uint32_t e = tid; e < DD_CAP * (L + 1); e += nt) { cvl[e] = -INFINITY; ckl[e] = 0; }  // empty candidate lists
     __syncthreads();
     // The register form first, unless there is none for this width (beyond 768 columns, or no room) or it has
     // already overflowed its DD_CAP candidates per column in this launch (dense inputs do so every time).
-    if (ring && !gave_up && W <= DD_WFOLD) {
+    if ((span || (ring && W <= DD_WFOLD)) && !gave_up) {
       if (wave == 0) {
         bool slow = true;
-        const float sc = nuss_wave_fast(W, L, S, trbp, trb_g, ring, lck, lane, &slow);
+        const float sc = span ? nuss_wave_span_t(L, isx ? nd.s_xs : nd.s_ys, trbp, tri, cvl, ckl, lck, lane, &slow)
+                              : nuss_wave_fast(W, L, S, trbp, trb_g, ring, lck, lane, &slow);
         if (!slow) nuss_traceback_fast(L, trbp, trb_g, lck, ss, (uint32_t*)P, lane);
         if (lane == 0) { s_fscore = sc; s_slow = slow ? 1u : 0u; }
       }
@@ -1507,8 +1520,10 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
   if (!resume) {
     nw_init_tr(L1, L2, trz);
     // sweep-order inputs of the three DPs, built once; the multiplier updates below keep them current
-    if (nd.s_x) dd_fill_scores(spanxy, L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_x);  // only foldings with a register form keep one
-    if (nd.s_y) dd_fill_scores(spanxy, L2, nd.p_y, nd.q_y, w_y, prm.th_s, nd.s_y);
+    if (nd.s_x) dd_fill_scores(false, L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_x);  // only foldings with a register form keep one
+    if (nd.s_y) dd_fill_scores(false, L2, nd.p_y, nd.q_y, w_y, prm.th_s, nd.s_y);
+    if (nd.s_xs) dd_fill_scores(true, L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_xs);  // the copy the span form reads
+    if (nd.s_ys) dd_fill_scores(true, L2, nd.p_y, nd.q_y, w_y, prm.th_s, nd.s_ys);
     dd_fill_nw(L1, L2, nd.p_z, nd.q_z, nd.pz_s, nd.qz_s);
   }
   __syncthreads();
@@ -1553,7 +1568,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     } else if (wave == 0) {
       bool slow = true;
       float sc = 0.0f;
-      if (spanxy && !gave_up_x) sc = nuss_wave_span_t(L1, nd.s_x, trxp, trix, cvx, ckx, lckx, lane, &slow);
+      if (spanxy && !gave_up_x) sc = nuss_wave_span_t(L1, nd.s_xs, trxp, trix, cvx, ckx, lckx, lane, &slow);
       else if (ringx && !gave_up_x && Wx <= DD_WFOLD) sc = nuss_wave_fast(Wx, L1, nd.s_x, trxp, nd.trb_x, ringx, lckx, lane, &slow);
       if (slow && lane == 0 && prm.stamps) nd.info[4] += 1;  // iterations that took the slower form
       if (lane == 0) { s_slowxy[0] = slow ? 1u : 0u; s_score[0] = sc; }  // slow: the span-ordered form below, by everybody
@@ -1573,7 +1588,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
         if (tryp) for (uint32_t e = (uint32_t)lane; e < nyw; e += 64) tryp[e] = 0;
         wave_lds_fence();
       }
-      if (spanxy && !gave_up_y) sc = nuss_wave_span_t(L2, nd.s_y, tryp, triy, cvy, cky, lcky, lane, &slow);
+      if (spanxy && !gave_up_y) sc = nuss_wave_span_t(L2, nd.s_ys, tryp, triy, cvy, cky, lcky, lane, &slow);
       else if (ringy && !gave_up_y && Wy <= DD_WFOLD) sc = nuss_wave_fast(Wy, L2, nd.s_y, tryp, nd.trb_y, ringy, lcky, lane, &slow);
       if (slow && lane == 0 && prm.stamps) nd.info[5] += 1;
       if (lane == 0) { s_slowxy[1] = slow ? 1u : 0u; s_score[1] = sc; }
@@ -1697,7 +1712,11 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
           const size_t o = (size_t)i * L1 + j;
           const float qn = nd.q_x[o] - eta * (tc - 1);
           nd.q_x[o] = qn;
-          if (nd.s_x && j >= i + 3) nd.s_x[fold_sidx(spanxy, L1, Wx, i, j)] = w_x * (nd.p_x[o] - prm.th_s) - qn;
+          if (j >= i + 3) {
+            const float sv = w_x * (nd.p_x[o] - prm.th_s) - qn;
+            if (nd.s_x) nd.s_x[fold_sidx(false, L1, Wx, i, j)] = sv;
+            if (nd.s_xs) nd.s_xs[fold_sidx(true, L1, Wx, i, j)] = sv;
+          }
         }
       }
       for (uint32_t e = nd.px_ptr[i]; e < nd.px_ptr[i + 1]; ++e) {
@@ -1709,7 +1728,11 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
           const size_t o = (size_t)i * L1 + jj;
           const float qn = nd.q_x[o] - eta * tc;
           nd.q_x[o] = qn;
-          if (nd.s_x && jj >= i + 3) nd.s_x[fold_sidx(spanxy, L1, Wx, i, jj)] = w_x * (nd.p_x[o] - prm.th_s) - qn;  // shorter spans stay 0 (dd_fill_scores)
+          if (jj >= i + 3) {  // shorter spans stay 0 (dd_fill_scores)
+            const float sv = w_x * (nd.p_x[o] - prm.th_s) - qn;
+            if (nd.s_x) nd.s_x[fold_sidx(false, L1, Wx, i, jj)] = sv;
+            if (nd.s_xs) nd.s_xs[fold_sidx(true, L1, Wx, i, jj)] = sv;
+          }
         }
       }
       const uint32_t kz = nd.z[i];
@@ -1744,7 +1767,11 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
           const size_t o = (size_t)k * L2 + l;
           const float qn = nd.q_y[o] - eta * (tc - 1);
           nd.q_y[o] = qn;
-          if (nd.s_y && l >= k + 3) nd.s_y[fold_sidx(spanxy, L2, Wy, k, l)] = w_y * (nd.p_y[o] - prm.th_s) - qn;
+          if (l >= k + 3) {
+            const float sv = w_y * (nd.p_y[o] - prm.th_s) - qn;
+            if (nd.s_y) nd.s_y[fold_sidx(false, L2, Wy, k, l)] = sv;
+            if (nd.s_ys) nd.s_ys[fold_sidx(true, L2, Wy, k, l)] = sv;
+          }
         }
       }
       for (uint32_t e = nd.py_ptr[k]; e < nd.py_ptr[k + 1]; ++e) {
@@ -1756,7 +1783,11 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
           const size_t o = (size_t)k * L2 + ll;
           const float qn = nd.q_y[o] - eta * tc;
           nd.q_y[o] = qn;
-          if (nd.s_y && ll >= k + 3) nd.s_y[fold_sidx(spanxy, L2, Wy, k, ll)] = w_y * (nd.p_y[o] - prm.th_s) - qn;
+          if (ll >= k + 3) {
+            const float sv = w_y * (nd.p_y[o] - prm.th_s) - qn;
+            if (nd.s_y) nd.s_y[fold_sidx(false, L2, Wy, k, ll)] = sv;
+            if (nd.s_ys) nd.s_ys[fold_sidx(true, L2, Wy, k, ll)] = sv;
+          }
         }
       }
     }

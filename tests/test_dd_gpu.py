@@ -152,6 +152,28 @@ def test_split_mode_and_shared_region(oracle, monkeypatch):
     assert ref.output == want and ref.dd_log == got.dd_log
 
 
+@pytest.mark.parametrize("n,length,density,t_max", [(6, 120, 0.02, 60), (5, 185, 0.015, 40), (4, 150, 0.06, 12)])
+def test_span_form_placements(oracle, monkeypatch, n, length, density, t_max):
+    """The span-ordered folding DP (lanes own rows, whole dp triangle in LDS) in its two placements -- both foldings side
+    by side in the node's workgroup (to ~165 columns each), or one folding per workgroup in a split launch (to 256
+    columns) -- and, with DAFS_HIP_DD_SPAN=0, the column-owning forms it replaces on the same inputs; the dense case
+    overflows the four candidate slots per column and takes the fallback.  All against the oracle, iteration log included."""
+    from dafs_amd import pipeline
+    from test_pct_gpu import random_bp
+    recs = synth.random_set(n, length, seed=77)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    bp = random_bp(seqs, 77, density=density)
+    want, (it, vi), got = _run_both(oracle, names, seqs, bp, t_max=t_max, slice_iters=7)
+    assert got.output == want
+    assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
+    monkeypatch.setenv("DAFS_HIP_DD_SPLIT", "0")  # span form only where both foldings fit the node's workgroup
+    one = pipeline.run(names, seqs, bp=bp, t_max=t_max, skip_uncoupled_folds=False)
+    assert one.output == want and one.dd_log == got.dd_log
+    monkeypatch.setenv("DAFS_HIP_DD_SPAN", "0")   # the column-owning forms
+    old = pipeline.run(names, seqs, bp=bp, t_max=t_max, level_sync=True, skip_uncoupled_folds=False)
+    assert old.output == want and old.dd_log == got.dd_log
+
+
 @pytest.mark.parametrize("length", [455, 600, 700])
 def test_fast_folding_with_codes_in_hbm(oracle, monkeypatch, length):
     """Alignments of ~430-510 columns: the nibble table of the traceback no longer fits LDS beside the rows in
