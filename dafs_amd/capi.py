@@ -127,6 +127,8 @@ _build_tree = _sig("dafs_host_build_tree", C.c_int, [C.c_uint32, C.c_void_p, C.c
 _set_mp = _sig("dafs_hip_set_mp", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
 _nodes_open = _sig("dafs_hip_nodes_open", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(NodeInput), C.POINTER(DDParams), C.c_void_p])
 _nodes_advance = _sig("dafs_hip_nodes_advance", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(DDParams), C.c_uint32, C.c_void_p])
+_nodes_round = _sig("dafs_hip_nodes_round", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(NodeInput), C.c_void_p, C.c_uint32, C.c_void_p,
+                                                      C.POINTER(DDParams), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p])
 _nodes_result = _sig("dafs_hip_nodes_result", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(NodeOutput)])
 _nodes_close = _sig("dafs_hip_nodes_close", C.c_int, [C.c_void_p])
 _nodes_memory = _sig("dafs_hip_nodes_memory", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
@@ -397,6 +399,26 @@ class Context:
         fin = np.zeros(len(h), np.uint8)
         check(_nodes_advance(self._h, len(h), h.ctypes.data, C.byref(prm), max_iterations, fin.ctypes.data))
         return fin.astype(bool)
+
+    def nodes_round(self, new_nodes, old_handles, prm, max_iterations, budget_us=0):
+        """one round: the open nodes (old_handles) advance while new_nodes (as in solve_nodes) are opened and started beside
+        them; at most max_iterations iterations each and, with budget_us, a common stop budget_us microseconds after the
+        round began.  Returns (handles of the new nodes, their (len1, len2), finished flags of the old, of the new)."""
+        n = len(new_nodes)
+        ins = (NodeInput * max(n, 1))()
+        keep = []
+        for b, (s1, m1, s2, m2) in enumerate(new_nodes):
+            s1 = np.ascontiguousarray(s1, np.uint32); s2 = np.ascontiguousarray(s2, np.uint32)
+            m1 = np.ascontiguousarray(m1, np.uint8); m2 = np.ascontiguousarray(m2, np.uint8)
+            keep.append((s1, s2, m1, m2))
+            ins[b].n1, ins[b].n2, ins[b].len1, ins[b].len2 = m1.shape[0], m2.shape[0], m1.shape[1], m2.shape[1]
+            ins[b].seq1, ins[b].seq2, ins[b].mask1, ins[b].mask2 = s1.ctypes.data, s2.ctypes.data, m1.ctypes.data, m2.ctypes.data
+        nh = np.zeros(max(n, 1), np.uint32)
+        h = np.ascontiguousarray(old_handles, np.uint32)
+        fo = np.zeros(max(len(h), 1), np.uint8); fn = np.zeros(max(n, 1), np.uint8)
+        check(_nodes_round(self._h, n, ins, nh.ctypes.data, len(h), h.ctypes.data if len(h) else None, C.byref(prm), max_iterations,
+                           budget_us, fo.ctypes.data, fn.ctypes.data))
+        return ([int(x) for x in nh[:n]], [(k[2].shape[1], k[3].shape[1]) for k in keep], fo[:len(h)].astype(bool), fn[:n].astype(bool))
 
     def nodes_result(self, handle, len1, len2):
         out = NodeOutput()

@@ -131,6 +131,7 @@ extern "C" int dafs_hip_create(int device, dafs_hip_ctx** out) {
   if (hip_check(hipStreamCreate(&c->stream))) { delete c; return DAFS_HIP_ENODEV; }
   // non-blocking: the folding must not be drawn into the implicit synchronisation of null-stream copies
   if (hip_check(hipStreamCreateWithFlags(&c->fold_stream, hipStreamNonBlocking))) { (void)hipStreamDestroy(c->stream); delete c; return DAFS_HIP_ENODEV; }
+  if (hip_check(hipStreamCreateWithFlags(&c->node_stream, hipStreamNonBlocking))) { (void)hipStreamDestroy(c->fold_stream); (void)hipStreamDestroy(c->stream); delete c; return DAFS_HIP_ENODEV; }
   int cus = 0;
   if (!hip_check(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) && cus > 0) c->num_cus = cus;
   *out = c;
@@ -142,6 +143,7 @@ extern "C" void dafs_hip_destroy(dafs_hip_ctx* c) {
   (void)hipSetDevice(c->device);
   c->free_all();
   (void)hipStreamDestroy(c->fold_stream);
+  (void)hipStreamDestroy(c->node_stream);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }

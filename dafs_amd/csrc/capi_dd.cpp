@@ -209,12 +209,18 @@ dd_params device_params(const dafs_dd_params* prm) {
   dp.skip_xy = prm->skip_uncoupled_folds ? 1 : 0;
   dp.debug_lose_folders = getenv("DAFS_HIP_DD_LOSE_FOLDERS") ? 1 : 0;
   dp.slice = 0;
+  dp.budget = 0; dp.t_ref = nullptr; dp.t_ref_write = 0;
   return dp;
 }
 
 // Builds nnodes resident nodes (appended to c->dd_open): geometry upload, profile averages, sparse lists and
 // consensus constraints (DAFS::align_alignments up to the solve_by_dd call, dafs.cpp:896-960).
-int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, const dd_params& dp) {
+// A lane = a stream with the node-descriptor and per-node-word buffers its launches use.  Lane 0 is the context's main
+// stream; dafs_hip_nodes_round sets up and starts new nodes on lane 1 while the open ones advance on lane 0.
+struct dd_lane { hipStream_t st; dev_buf<dd_node>* d_nodes; dev_buf<uint32_t>* d_paused; int id; };
+dd_lane lane_of(dafs_hip_ctx* c, int k) { return k == 0 ? dd_lane{c->stream, &c->d_nodes, &c->d_paused, 0} : dd_lane{c->node_stream, &c->d_nodes2, &c->d_paused2, 1}; }
+
+int nodes_open(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const dafs_node_input* in, const dd_params& dp) {
   const mp_store& mps = c->mp[c->cur_mp];
   const bp_store& bps = c->bp[c->cur_bp];
   const uint32_t nseq = (uint32_t)c->len.size();
@@ -359,7 +365,7 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
       }
     }
     for (const region& r : fills)
-      if (hip_check(hipMemsetAsync(cv.base + r.off, r.value, r.bytes, c->stream))) return DAFS_HIP_ELAUNCH;
+      if (hip_check(hipMemsetAsync(cv.base + r.off, r.value, r.bytes, ln.st))) return DAFS_HIP_ELAUNCH;
     // the geometry arrays were carved first and back to back: one upload of the head of the block brings them all
     {
       const size_t head = (size_t)((const uint8_t*)(nd.idxoff2 + ni.n2) - cv.base);
@@ -372,22 +378,22 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
       put(nd.rank1, g1[b].rank.data(), g1[b].rank.size() * 4); put(nd.rank2, g2[b].rank.data(), g2[b].rank.size() * 4);
       put(nd.idx1, g1[b].idx.data(), g1[b].idx.size() * 4); put(nd.idx2, g2[b].idx.data(), g2[b].idx.size() * 4);
       put(nd.idxoff1, g1[b].idxoff.data(), (size_t)ni.n1 * 4); put(nd.idxoff2, g2[b].idxoff.data(), (size_t)ni.n2 * 4);
-      if (hip_check(hipMemcpyAsync(cv.base, blob.data(), head, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
+      if (hip_check(hipMemcpyAsync(cv.base, blob.data(), head, hipMemcpyHostToDevice, ln.st))) return DAFS_HIP_ELAUNCH;
     }
   }
   int rc;
-  if ((rc = c->d_nodes.upload(nodes.data(), nnodes, c->stream))) return rc;  // synchronises: host vectors stay valid until here
+  if ((rc = ln.d_nodes->upload(nodes.data(), nnodes, ln.st))) return rc;  // synchronises: host vectors stay valid until here
   const mp_store_dev mpv = mps.view(c->d_len.ptr, nseq);
   const bp_store_dev bpv = bps.view();
   uint32_t max_len = 0;
   for (uint32_t b = 0; b < nnodes; ++b) max_len = std::max(max_len, std::max(in[b].len1, in[b].len2));
-  if ((rc = dd_avg_launch(c->d_nodes.ptr, nnodes, max_len, mpv, bpv, force_wide ? 1 : 0, c->stream))) return rc;
-  if ((rc = c->d_paused.reserve(nnodes))) return rc;  // doubles as the landing place of the per-node counts
-  if ((rc = dd_lists_launch(c->d_nodes.ptr, nnodes, force_wide ? 0 : max_len, dp, c->d_paused.ptr, c->stream))) return rc;
+  if ((rc = dd_avg_launch(ln.d_nodes->ptr, nnodes, max_len, mpv, bpv, force_wide ? 1 : 0, ln.st))) return rc;
+  if ((rc = ln.d_paused->reserve(nnodes))) return rc;  // doubles as the landing place of the per-node counts
+  if ((rc = dd_lists_launch(ln.d_nodes->ptr, nnodes, force_wide ? 0 : max_len, dp, ln.d_paused->ptr, ln.st))) return rc;
   // ---- consensus base-pair counts -> each node's second block ----
   std::vector<uint32_t> counts(nnodes);
-  if (hip_check(hipMemcpyAsync(counts.data(), c->d_paused.ptr, (size_t)nnodes * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
-  if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
+  if (hip_check(hipMemcpyAsync(counts.data(), ln.d_paused->ptr, (size_t)nnodes * 4, hipMemcpyDeviceToHost, ln.st))) return DAFS_HIP_ELAUNCH;
+  if (hip_check(hipStreamSynchronize(ln.st))) return DAFS_HIP_ELAUNCH;
   for (uint32_t b = 0; b < nnodes; ++b) {
     const uint32_t ncbp = counts[b];
     carver cb;
@@ -403,16 +409,24 @@ int nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_node_input* in, cons
       }
     }
   }
-  if ((rc = c->d_nodes.upload(nodes.data(), nnodes, c->stream))) return rc;
-  if ((rc = dd_cbp_fill_launch(c->d_nodes.ptr, nnodes, force_wide ? 0 : max_len, dp, c->stream))) return rc;
+  if ((rc = ln.d_nodes->upload(nodes.data(), nnodes, ln.st))) return rc;
+  if ((rc = dd_cbp_fill_launch(ln.d_nodes->ptr, nnodes, force_wide ? 0 : max_len, dp, ln.st))) return rc;
   for (uint32_t b = 0; b < nnodes; ++b) c->dd_open.push_back({nodes[b], lds[b], split_lds[b], false, {blk0[b], blk1[b]}, {blk0_bytes[b], blk1_bytes[b]}, false, false});
   return DAFS_HIP_OK;
 }
 
 // One launch of the subgradient loop over the given resident nodes; finished[k] tells which of them are done.
-int nodes_advance(dafs_hip_ctx* c, uint32_t n, const uint32_t* handles, dd_params dp, uint32_t max_iterations, uint8_t* finished) {
+// In two halves, so that launches on two lanes can be in flight together: advance_launch enqueues the kernel and the
+// copy of the per-node words, advance_collect waits for them.
+struct advance_state { std::vector<uint32_t> who, handles; const uint32_t* paused = nullptr; bool launched = false; };
+
+int advance_launch(dafs_hip_ctx* c, const dd_lane& ln, uint32_t n, const uint32_t* handles, dd_params dp, uint32_t max_iterations, uint8_t* finished,
+                   advance_state& stt) {
   std::vector<dd_node> nodes;
-  std::vector<uint32_t> who;
+  std::vector<uint32_t>& who = stt.who;
+  who.clear();
+  stt.handles.assign(handles, handles + n);
+  stt.launched = false;
   size_t lds_max = 0;
   for (uint32_t k = 0; k < n; ++k) {
     if (handles[k] >= c->dd_open.size()) return DAFS_HIP_EINVAL;
@@ -437,7 +451,7 @@ int nodes_advance(dafs_hip_ctx* c, uint32_t n, const uint32_t* handles, dd_param
       nodes[b].split = 1;
       nodes[b].lds_flags &= (1u | 32u);  // the leader keeps the alignment DP only
       lds_max = std::max(lds_max, on.split_lds);
-      if (hip_check(hipMemsetAsync(nodes[b].sync, 0, 4, c->stream))) return DAFS_HIP_ELAUNCH;  // clear the exit mark of the last launch
+      if (hip_check(hipMemsetAsync(nodes[b].sync, 0, 4, ln.st))) return DAFS_HIP_ELAUNCH;  // clear the exit mark of the last launch
     } else {
       nodes[b].split = 0;
       lds_max = std::max(lds_max, on.lds);
@@ -445,19 +459,36 @@ int nodes_advance(dafs_hip_ctx* c, uint32_t n, const uint32_t* handles, dd_param
   }
   dp.slice = max_iterations;
   int rc;
-  if ((rc = c->d_nodes.upload(nodes.data(), nodes.size(), c->stream))) return rc;
-  if ((rc = c->d_paused.reserve(nodes.size()))) return rc;
-  if ((rc = dd_solve_launch(c->d_nodes.ptr, (uint32_t)nodes.size(), dp, lds_max, split, c->d_paused.ptr, c->stream))) return rc;
-  std::vector<uint32_t> paused(nodes.size());
-  if (hip_check(hipMemcpyAsync(paused.data(), c->d_paused.ptr, nodes.size() * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
-  if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
-  for (size_t b = 0; b < nodes.size(); ++b) {
-    const bool done = paused[b] == 0;
-    if (paused[b] == 2) c->dd_open[handles[who[b]]].no_split = true;  // its folders were lost: from now on the one-workgroup form
-    c->dd_open[handles[who[b]]].finished = done;
-    if (finished) finished[who[b]] = done ? 1 : 0;
-  }
+  if ((rc = ln.d_nodes->upload(nodes.data(), nodes.size(), ln.st))) return rc;
+  if ((rc = ln.d_paused->reserve(nodes.size()))) return rc;
+  if ((rc = dd_solve_launch(ln.d_nodes->ptr, (uint32_t)nodes.size(), dp, lds_max, split, ln.d_paused->ptr, ln.st))) return rc;
+  uint32_t* landing = c->pinned_words(ln.id, nodes.size());
+  if (!landing) return DAFS_HIP_ENOMEM;
+  stt.paused = landing;
+  if (hip_check(hipMemcpyAsync(landing, ln.d_paused->ptr, nodes.size() * 4, hipMemcpyDeviceToHost, ln.st))) return DAFS_HIP_ELAUNCH;
+  stt.launched = true;
   return DAFS_HIP_OK;
+}
+
+int advance_collect(dafs_hip_ctx* c, const dd_lane& ln, advance_state& stt, uint8_t* finished) {
+  if (!stt.launched) return DAFS_HIP_OK;
+  if (hip_check(hipStreamSynchronize(ln.st))) return DAFS_HIP_ELAUNCH;
+  for (size_t b = 0; b < stt.who.size(); ++b) {
+    const uint32_t h = stt.handles[stt.who[b]];
+    const bool done = stt.paused[b] == 0;
+    if (stt.paused[b] == 2) c->dd_open[h].no_split = true;  // its folders were lost: from now on the one-workgroup form
+    c->dd_open[h].finished = done;
+    if (finished) finished[stt.who[b]] = done ? 1 : 0;
+  }
+  stt.launched = false;
+  return DAFS_HIP_OK;
+}
+
+int nodes_advance(dafs_hip_ctx* c, uint32_t n, const uint32_t* handles, dd_params dp, uint32_t max_iterations, uint8_t* finished) {
+  advance_state stt;
+  const dd_lane ln = lane_of(c, 0);
+  const int rc = advance_launch(c, ln, n, handles, dp, max_iterations, finished, stt);
+  return rc ? rc : advance_collect(c, ln, stt, finished);
 }
 
 int nodes_result(dafs_hip_ctx* c, uint32_t handle, dafs_node_output* out, bool stamps) {
@@ -506,7 +537,7 @@ extern "C" int dafs_hip_nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_
   if (!c || !in || !prm || !handles || nnodes == 0) return DAFS_HIP_EINVAL;
   if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
   const uint32_t first = (uint32_t)c->dd_open.size();
-  const int rc = nodes_open(c, nnodes, in, device_params(prm));
+  const int rc = nodes_open(c, lane_of(c, 0), nnodes, in, device_params(prm));
   if (rc) { c->dd_open.resize(first); return rc; }
   for (uint32_t b = 0; b < nnodes; ++b) handles[b] = first + b;
   return DAFS_HIP_OK;
@@ -517,6 +548,46 @@ extern "C" int dafs_hip_nodes_advance(dafs_hip_ctx* c, uint32_t n, const uint32_
   if (!c || !handles || !prm || n == 0) return DAFS_HIP_EINVAL;
   if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
   return nodes_advance(c, n, handles, device_params(prm), max_iterations, finished);
+}
+
+// One round of the progressive phase in a single call: the open nodes advance (lane 0) while the nodes whose children have
+// just finished are set up and started beside them (lane 1) -- their set-up kernels (averages, lists, constraints: ~0.8 ms
+// a call, one or two workgroups busy) no longer stand between two launches of the solver.  With budget_us > 0 every node of
+// the round also stops at the same moment (dd_params::budget), so the late starters do not stretch the round.
+extern "C" int dafs_hip_nodes_round(dafs_hip_ctx* c, uint32_t n_new, const dafs_node_input* in, uint32_t* new_handles, uint32_t n_old,
+                                    const uint32_t* old_handles, const dafs_dd_params* prm, uint32_t max_iterations, uint32_t budget_us,
+                                    uint8_t* finished_old, uint8_t* finished_new) {
+  if (!c || !prm || (n_new && (!in || !new_handles)) || (n_old && !old_handles) || (n_new == 0 && n_old == 0)) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  dd_params dp = device_params(prm);
+  dp.budget = (unsigned long long)budget_us * 100ull;  // wall_clock64 ticks at 100 MHz
+  int rc = DAFS_HIP_OK;
+  advance_state st_old, st_new;
+  const dd_lane l0 = lane_of(c, 0);
+  // without open nodes there is nothing to overlap with: everything on the main lane
+  const dd_lane l1 = n_old ? lane_of(c, 1) : l0;
+  if (n_old) {
+    if (dp.budget) {
+      if ((rc = c->d_tref.reserve(1))) return rc;
+      if (hip_check(hipMemsetAsync(c->d_tref.ptr, 0, sizeof(unsigned long long), l0.st))) return DAFS_HIP_ELAUNCH;
+      dp.t_ref = c->d_tref.ptr;
+      dp.t_ref_write = 1;
+    }
+    if ((rc = advance_launch(c, l0, n_old, old_handles, dp, max_iterations, finished_old, st_old))) return rc;
+  }
+  if (n_new) {
+    const uint32_t first = (uint32_t)c->dd_open.size();
+    dd_params dpn = dp;
+    dpn.t_ref_write = 0;  // a late starter takes the round's reference tick (none when it runs alone)
+    if (!n_old) dpn.t_ref = nullptr;
+    rc = nodes_open(c, l1, n_new, in, dpn);
+    if (rc) { c->dd_open.resize(first); (void)advance_collect(c, l0, st_old, finished_old); return rc; }
+    for (uint32_t b = 0; b < n_new; ++b) new_handles[b] = first + b;
+    rc = advance_launch(c, l1, n_new, new_handles, dpn, max_iterations, finished_new, st_new);
+  }
+  const int rc0 = advance_collect(c, l0, st_old, finished_old);
+  const int rc1 = n_new ? advance_collect(c, l1, st_new, finished_new) : DAFS_HIP_OK;
+  return rc ? rc : (rc0 ? rc0 : rc1);
 }
 
 extern "C" int dafs_hip_nodes_result(dafs_hip_ctx* c, uint32_t handle, dafs_node_output* out) {
@@ -551,7 +622,7 @@ extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs
   if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
   if (!c->dd_open.empty()) return DAFS_HIP_EINVAL;
   const dd_params dp = device_params(prm);
-  int rc = nodes_open(c, nnodes, in, dp);
+  int rc = nodes_open(c, lane_of(c, 0), nnodes, in, dp);
   std::vector<uint32_t> handles(nnodes);
   for (uint32_t b = 0; b < nnodes; ++b) handles[b] = b;
   // one launch runs every node to its end -- unless a split node lost its folding workgroups and was parked for the

@@ -92,6 +92,7 @@ struct dafs_hip_ctx {
   int num_cus = 256;  // compute units of the device (co-residency bound of the split node solver)
   hipStream_t stream = nullptr;
   hipStream_t fold_stream = nullptr;  // the per-sequence folding runs here, beside the pair / consistency kernels
+  hipStream_t node_stream = nullptr;  // dafs_hip_nodes_round: new nodes are set up and started here while the open ones advance on `stream`
   bool fold_pending = false;          // dafs_hip_fold_posteriors_begin without its _end
   float fold_th = 0.0f;
   std::vector<uint8_t> fold_batch;    // the cf_batch of the pending job (contrafold.h), kept opaque here
@@ -125,6 +126,22 @@ struct dafs_hip_ctx {
   dafs::dev_buf<uint8_t> work, work2;
   dafs::dev_buf<dafs::dd_node> d_nodes;
   dafs::dev_buf<uint32_t> d_paused;  // per node of a launch: still unfinished
+  dafs::dev_buf<dafs::dd_node> d_nodes2;  // the same pair for the second lane of dafs_hip_nodes_round
+  dafs::dev_buf<uint32_t> d_paused2;
+  dafs::dev_buf<unsigned long long> d_tref;  // start tick of a round's first launch: the lanes of a round share one deadline
+  // pinned landing places of the per-node words of a launch, one per lane: a copy into pageable memory would make the
+  // "asynchronous" copy wait for the kernel in front of it, and the second lane could not start beside the first
+  uint32_t* h_paused[2] = {nullptr, nullptr};
+  size_t h_paused_cap[2] = {0, 0};
+  uint32_t* pinned_words(int lane, size_t n) {
+    if (n <= h_paused_cap[lane] && h_paused[lane]) return h_paused[lane];
+    if (h_paused[lane]) (void)hipHostFree(h_paused[lane]);
+    h_paused[lane] = nullptr; h_paused_cap[lane] = 0;
+    const size_t want = n + n / 2 + 256;
+    if (dafs::hip_check(hipHostMalloc((void**)&h_paused[lane], want * sizeof(uint32_t), hipHostMallocDefault))) return nullptr;
+    h_paused_cap[lane] = want;
+    return h_paused[lane];
+  }
   // resident tree nodes (dafs_hip_nodes_open / _advance / _result / _close).  Their device memory comes from large
   // chunks that are kept for the next phase; a node's blocks go back to an address-ordered free list (neighbours
   // merged) as soon as its result has been copied out (dafs_hip_nodes_result), so a progressive run holds the nodes
@@ -196,7 +213,8 @@ struct dafs_hip_ctx {
 
   void free_all() {
     codes.release(); d_len.release(); d_seq_rp_off.release(); tasks.release(); scratch.release(); task_sim.release();
-    counters.release(); d_sim.release(); d_pair_x.release(); d_pair_y.release(); work.release(); work2.release(); d_nodes.release(); d_paused.release(); dd_release();
+    counters.release(); d_sim.release(); d_pair_x.release(); d_pair_y.release(); work.release(); work2.release(); d_nodes.release(); d_paused.release(); d_nodes2.release(); d_paused2.release(); d_tref.release(); dd_release();
+    for (int k = 0; k < 2; ++k) { if (h_paused[k]) (void)hipHostFree(h_paused[k]); h_paused[k] = nullptr; h_paused_cap[k] = 0; }
     d_cf_params.release(); cf_seqs.release(); cf_codes.release(); cf_iws.release(); cf_cons.release(); cf_fws.release(); cf_post.release(); cf_logz.release();
     for (int k = 0; k < 2; ++k) { mp[k].release(); bp[k].release(); }
   }

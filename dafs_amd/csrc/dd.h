@@ -68,6 +68,13 @@ struct dd_params {
   int debug_lose_folders;  // DAFS_HIP_DD_LOSE_FOLDERS=1 (tests): the leader of a split node treats its folders as lost at once
   uint32_t slice;  // at most this many iterations per launch (0 = run to the end); a node that is cut short is
                    // marked paused and continues from where it stopped at the next launch
+  // A second bound on a launch, in time: a node also pauses at the first iteration end past `budget` ticks (100 MHz,
+  // wall_clock64) after the reference tick -- its workgroup's own start, or, when t_ref is given, the tick the round's
+  // first launch left there (t_ref_write: this launch is the one that leaves it), so that launches started at different
+  // moments of a round stop together (dafs_hip_nodes_round).  0 = no time bound.
+  unsigned long long budget;
+  unsigned long long* t_ref;
+  int t_ref_write;
 };
 
 int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_store_dev mp, bp_store_dev bp, int one_row, hipStream_t st);

@@ -1535,6 +1535,20 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
   if (tid == 0) { s_tky = 0; s_tkz = 0; }
 #define DD_TICK(k) if (prm.stamps && tid == 0) { const unsigned long long now = wall_clock64(); tk[k] += now - t_prev; t_prev = now; }
   if (prm.stamps && tid == 0) t_prev = wall_clock64();
+  // time bound of the launch (dd_params::budget); meaningful in thread 0
+  unsigned long long deadline = 0;
+  if (prm.budget && tid == 0) {
+    unsigned long long t0 = wall_clock64();
+    if (prm.t_ref) {
+      if (prm.t_ref_write) {
+        if (blockIdx.x == 0) __hip_atomic_store(prm.t_ref, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        const unsigned long long ref = __hip_atomic_load(prm.t_ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ref) t0 = ref;
+      }
+    }
+    deadline = t0 + prm.budget;
+  }
   uint32_t ran = 0;
   bool paused = false;
   // prm.skip_xy: a node without consensus base pairs has nothing that couples its three subproblems, and the
@@ -1817,10 +1831,12 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
         s_prev = s;
       }
       if (s_bad) stop = 1;
+      if (!stop && prm.budget && t + 1 != prm.t_max && wall_clock64() >= deadline) stop = 2;  // out of time: pause here
       s_stop = stop;
     }
     __syncthreads();
     DD_TICK(5);
+    if (s_stop == 2) { paused = true; ++t; break; }  // to be continued, like a node whose slice ran out
     if (s_stop) break;
     if (prm.slice && ++ran == prm.slice && t + 1 != prm.t_max) { paused = true; ++t; break; }  // to be continued
   }

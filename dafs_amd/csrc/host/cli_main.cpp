@@ -489,10 +489,11 @@ int run(const Options& o) {
   }
   float s = 0.0f;
   {
-    // The nodes stay resident on the device (dafs_hip_nodes_*): every round opens the nodes whose children
-    // are ready, advances all open nodes by at most kSlice iterations in one launch and merges the
-    // finished ones, so a node that needs the full iteration budget does not hold back its level.
-    const uint32_t kSlice = 32;
+    // The nodes stay resident on the device (dafs_hip_nodes_*).  A round is one call (dafs_hip_nodes_round): the open
+    // nodes advance while the nodes whose children have just finished are set up and started beside them, and all of
+    // them stop together after kRoundUs microseconds, so a node that needs the full iteration budget does not hold
+    // back its level and the set-up of new nodes does not stand between two launches.
+    const uint32_t kRoundUs = getenv("DAFS_ROUND_US") ? (uint32_t)atoi(getenv("DAFS_ROUND_US")) : 2500u;
     struct Open { uint node; uint32_t handle; NodeJob job; };
     std::vector<Open> open;
     size_t remaining = tree.size() - N;
@@ -501,31 +502,28 @@ int run(const Options& o) {
       std::vector<uint> ready;
       for (uint i = N; i < tree.size(); ++i)
         if (!done[i] && !opened[i] && done[tree[i].second.first] && done[tree[i].second.second]) ready.push_back(i);
-      if (!ready.empty()) {
-        const size_t first = open.size();
-        std::vector<dafs_node_input> in(ready.size());
-        for (size_t b = 0; b < ready.size(); ++b) {
-          open.push_back(Open{ready[b], 0, NodeJob()});
-          opened[ready[b]] = true;
-        }
-        for (size_t b = 0; b < ready.size(); ++b) {
-          const ALN &a1 = aln[tree[ready[b]].second.first], &a2 = aln[tree[ready[b]].second.second];
-          NodeJob& j = open[first + b].job;
-          flatten(a1, j.s1, j.m1);
-          flatten(a2, j.s2, j.m2);
-          in[b].n1 = (uint32_t)a1.size(); in[b].n2 = (uint32_t)a2.size();
-          in[b].len1 = (uint32_t)a1[0].second.size(); in[b].len2 = (uint32_t)a2[0].second.size();
-          in[b].seq1 = j.s1.data(); in[b].seq2 = j.s2.data(); in[b].mask1 = j.m1.data(); in[b].mask2 = j.m2.data();
-          j.x.resize(in[b].len1); j.y.resize(in[b].len2); j.z.resize(in[b].len1);
-        }
-        std::vector<uint32_t> handles(ready.size());
-        check(dafs_hip_nodes_open(ctx, (uint32_t)ready.size(), in.data(), &prm_prog, handles.data()));
-        for (size_t b = 0; b < ready.size(); ++b) open[first + b].handle = handles[b];
+      const size_t n_old = open.size();
+      std::vector<dafs_node_input> in(ready.size() ? ready.size() : 1);
+      for (size_t b = 0; b < ready.size(); ++b) {
+        open.push_back(Open{ready[b], 0, NodeJob()});
+        opened[ready[b]] = true;
       }
-      std::vector<uint32_t> handles(open.size());
-      std::vector<uint8_t> fin(open.size());
-      for (size_t k = 0; k < open.size(); ++k) handles[k] = open[k].handle;
-      check(dafs_hip_nodes_advance(ctx, (uint32_t)open.size(), handles.data(), &prm_prog, kSlice, fin.data()));
+      for (size_t b = 0; b < ready.size(); ++b) {
+        const ALN &a1 = aln[tree[ready[b]].second.first], &a2 = aln[tree[ready[b]].second.second];
+        NodeJob& j = open[n_old + b].job;
+        flatten(a1, j.s1, j.m1);
+        flatten(a2, j.s2, j.m2);
+        in[b].n1 = (uint32_t)a1.size(); in[b].n2 = (uint32_t)a2.size();
+        in[b].len1 = (uint32_t)a1[0].second.size(); in[b].len2 = (uint32_t)a2[0].second.size();
+        in[b].seq1 = j.s1.data(); in[b].seq2 = j.s2.data(); in[b].mask1 = j.m1.data(); in[b].mask2 = j.m2.data();
+        j.x.resize(in[b].len1); j.y.resize(in[b].len2); j.z.resize(in[b].len1);
+      }
+      std::vector<uint32_t> old_handles(n_old ? n_old : 1), new_handles(ready.size() ? ready.size() : 1);
+      std::vector<uint8_t> fin(open.size() ? open.size() : 1, 0);
+      for (size_t k = 0; k < n_old; ++k) old_handles[k] = open[k].handle;
+      check(dafs_hip_nodes_round(ctx, (uint32_t)ready.size(), in.data(), new_handles.data(), (uint32_t)n_old, old_handles.data(), &prm_prog, 0,
+                                 kRoundUs, fin.data(), fin.data() + n_old));
+      for (size_t b = 0; b < ready.size(); ++b) open[n_old + b].handle = new_handles[b];
       std::vector<Open> still;
       for (size_t k = 0; k < open.size(); ++k) {
         if (!fin[k]) { still.push_back(std::move(open[k])); continue; }

@@ -87,8 +87,8 @@ class Result:
 
 
 def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25, w_pct_s=0.25, th_a=0.01,
-        th_s=0.2, th_s1=None, align_model=capi.ALIGN_PROBCONS, force_iters=0, timers=None, level_sync=False, slice_iters=32,
-        mp=None, skip_uncoupled_folds=True, shard=None):
+        th_s=0.2, th_s1=None, align_model=capi.ALIGN_PROBCONS, force_iters=0, timers=None, level_sync=False, slice_iters=None,
+        mp=None, skip_uncoupled_folds=True, shard=None, round_us=None):
     """The whole run.  bp: per-sequence (rowptr, col, val) base-pairing rows (--fold-aux); None
     computes them with the device fold model.  mp: supplied matching probabilities (--align-aux), see Context.set_mp.
     shard: (torch.distributed module, torch device) of an initialised process group -- phase 1 (folds, pair posteriors,
@@ -110,7 +110,7 @@ def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25
     score, left, right = capi.build_tree(sim)  # same code as the command line (build_tree below is its Python twin, kept for the CPU tests)
     t.append(time.perf_counter())
     return _phase2(ctx, own, names, seqs, n, sim, score, left, right, t, w, eta0, t_max, th_a, th_s, th_s1, force_iters, level_sync, slice_iters,
-                   skip_uncoupled_folds)
+                   skip_uncoupled_folds, round_us)
 
 
 def _phase1_local(ctx, seqs, bp, mp, align_model, th_a, w_pct_a, w_pct_s, t):
@@ -138,7 +138,7 @@ def _phase1_local(ctx, seqs, bp, mp, align_model, th_a, w_pct_a, w_pct_s, t):
 
 
 def _phase2(ctx, own, names, seqs, n, sim, score, left, right, t, w, eta0, t_max, th_a, th_s, th_s1, force_iters, level_sync, slice_iters,
-            skip_uncoupled_folds):
+            skip_uncoupled_folds, round_us=None):
     import time
     res = Result()
     res.sim = sim
@@ -171,21 +171,26 @@ def _phase2(ctx, own, names, seqs, n, sim, score, left, right, t, w, eta0, t_max
             pending = [i for i in pending if i not in ready]
             res.levels += 1
     else:
+        # A round = one call: the open nodes advance while the nodes whose children finished in the last round are set up
+        # and started beside them (Context.nodes_round).  A round ends after `round_us` microseconds (all its nodes stop at
+        # the next iteration end) or, when slice_iters is given, after that many iterations of every node (tests cut the
+        # loop in many ways: the results do not depend on it).
+        if slice_iters is None and round_us is None:
+            round_us = int(os.environ.get("DAFS_ROUND_US", "2500"))
         open_nodes = {}  # node -> (handle, len1, len2)
         while pending or open_nodes:
             ready = [i for i in pending if left[i] in aln and right[i] in aln]
-            if ready:
-                if trace:
-                    print("open", [(i, aln[left[i]][1].shape, aln[right[i]][1].shape) for i in ready], file=sys.stderr, flush=True)
-                hs, dims = ctx.nodes_open([(aln[left[i]][0], aln[left[i]][1], aln[right[i]][0], aln[right[i]][1]) for i in ready], prm)
-                for i, h, d in zip(ready, hs, dims):
-                    open_nodes[i] = (h, d[0], d[1])
-                pending = [i for i in pending if i not in ready]
+            if ready and trace:
+                print("open", [(i, aln[left[i]][1].shape, aln[right[i]][1].shape) for i in ready], file=sys.stderr, flush=True)
+            pending = [i for i in pending if i not in ready]
             ids = sorted(open_nodes)
             t_round = time.perf_counter()
-            fin = ctx.nodes_advance([open_nodes[i][0] for i in ids], prm, slice_iters)
-            res.rounds.append((time.perf_counter() - t_round, [(i, open_nodes[i][1], open_nodes[i][2]) for i in ids]))
-            for i, f in zip(ids, fin):
+            hs, dims, fin_old, fin_new = ctx.nodes_round([(aln[left[i]][0], aln[left[i]][1], aln[right[i]][0], aln[right[i]][1]) for i in ready],
+                                                         [open_nodes[i][0] for i in ids], prm, slice_iters or 0, round_us or 0)
+            for i, h, d in zip(ready, hs, dims):
+                open_nodes[i] = (h, d[0], d[1])
+            res.rounds.append((time.perf_counter() - t_round, [(i, open_nodes[i][1], open_nodes[i][2]) for i in ids + ready]))
+            for i, f in list(zip(ids, fin_old)) + list(zip(ready, fin_new)):
                 if not f:
                     continue
                 h, l1, l2 = open_nodes.pop(i)

@@ -310,6 +310,13 @@ int dafs_hip_solve_nodes(dafs_hip_ctx* ctx, uint32_t nnodes, const dafs_node_inp
 int dafs_hip_nodes_open(dafs_hip_ctx* ctx, uint32_t nnodes, const dafs_node_input* in, const dafs_dd_params* prm, uint32_t* handles);
 int dafs_hip_nodes_advance(dafs_hip_ctx* ctx, uint32_t n, const uint32_t* handles, const dafs_dd_params* prm, uint32_t max_iterations,
                            uint8_t* finished);
+/* One round in a single call: the n_old open nodes advance while the n_new nodes whose children have just finished are
+ * opened and started beside them on a second stream (their handles come back in new_handles).  Every node runs at most
+ * max_iterations iterations and, when budget_us > 0, stops at the first iteration end past budget_us microseconds after
+ * the round began, late starters included.  Results are those of the calls above, bit for bit.                          */
+int dafs_hip_nodes_round(dafs_hip_ctx* ctx, uint32_t n_new, const dafs_node_input* in, uint32_t* new_handles, uint32_t n_old,
+                         const uint32_t* old_handles, const dafs_dd_params* prm, uint32_t max_iterations, uint32_t budget_us,
+                         uint8_t* finished_old, uint8_t* finished_new);
 int dafs_hip_nodes_result(dafs_hip_ctx* ctx, uint32_t handle, dafs_node_output* out);
 int dafs_hip_nodes_close(dafs_hip_ctx* ctx);
 /* Device memory of the resident nodes (diagnostics): bytes reserved from the device, bytes held by open nodes now, and

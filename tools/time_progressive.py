@@ -17,7 +17,7 @@ def wrap(name):
         acc[name + "#"] = acc.get(name + "#", 0) + 1
         return r
     setattr(capi.Context, name, g)
-for nm in ("nodes_open", "nodes_advance", "nodes_result", "nodes_close"):
+for nm in ("nodes_round", "nodes_open", "nodes_advance", "nodes_result", "nodes_close"):
     wrap(nm)
 res = pipeline.run(names, seqs, ctx=ctx)
 print("progressive %.1f ms" % (1e3 * res.seconds["progressive"]), {k: (round(1e3 * v, 1) if not k.endswith("#") else v) for k, v in acc.items()})

@@ -17,7 +17,7 @@ for rep in range(2):
     tree = capi.build_tree(sim); t.append(time.perf_counter())
     if rep:
         print("set_seq %.1f ms | fold %.1f | pair(L1 call) %.1f | pct %.1f | tree %.1f" % tuple(1e3 * (b - a) for a, b in zip(t, t[1:])))
-res = pipeline.run(names, seqs, ctx=ctx, level_sync=os.environ.get("DAFS_LEVEL_SYNC") == "1", slice_iters=int(os.environ.get("DAFS_SLICE", "32")),
+res = pipeline.run(names, seqs, ctx=ctx, level_sync=os.environ.get("DAFS_LEVEL_SYNC") == "1", slice_iters=(int(os.environ["DAFS_SLICE"]) if "DAFS_SLICE" in os.environ else None),
                    skip_uncoupled_folds=os.environ.get("DAFS_SKIP", "1") != "0")
 print({k: round(v, 3) for k, v in res.seconds.items()}, "levels", res.levels, "cols", len(res.rows[0]))
 its = sorted(v[0] for v in res.dd_log.values())
