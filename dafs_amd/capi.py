@@ -89,6 +89,7 @@ _fold_posterior_dense = _sig("dafs_hip_fold_posterior_dense", C.c_int,
 _consistency = _sig("dafs_hip_consistency", C.c_int, [C.c_void_p, C.c_float, C.c_float])
 _consistency_match = _sig("dafs_hip_consistency_match", C.c_int, [C.c_void_p, C.c_float])
 _consistency_bp = _sig("dafs_hip_consistency_bp", C.c_int, [C.c_void_p, C.c_float])
+_fourway_consistency = _sig("dafs_hip_fourway_consistency", C.c_int, [C.c_void_p, C.c_float])
 _consistency_match_range = _sig("dafs_hip_consistency_match_range", C.c_int, [C.c_void_p, C.c_float, C.c_uint64, C.c_uint64])
 _mp_install = _sig("dafs_hip_mp_install", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
 _fold_begin = _sig("dafs_hip_fold_posteriors_begin", C.c_int, [C.c_void_p, C.c_int, C.c_float])
@@ -97,7 +98,8 @@ _fold_end = _sig("dafs_hip_fold_posteriors_end", C.c_int, [C.c_void_p])
 
 class NodeInput(C.Structure):
     _fields_ = [("n1", C.c_uint32), ("n2", C.c_uint32), ("len1", C.c_uint32), ("len2", C.c_uint32),
-                ("seq1", C.c_void_p), ("seq2", C.c_void_p), ("mask1", C.c_void_p), ("mask2", C.c_void_p)]
+                ("seq1", C.c_void_p), ("seq2", C.c_void_p), ("mask1", C.c_void_p), ("mask2", C.c_void_p),
+                ("p_x", C.c_void_p), ("p_y", C.c_void_p)]
 
 
 class NodeOutput(C.Structure):
@@ -132,6 +134,7 @@ _nodes_round = _sig("dafs_hip_nodes_round", C.c_int, [C.c_void_p, C.c_uint32, C.
 _nodes_result = _sig("dafs_hip_nodes_result", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(NodeOutput)])
 _nodes_close = _sig("dafs_hip_nodes_close", C.c_int, [C.c_void_p])
 _nodes_memory = _sig("dafs_hip_nodes_memory", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
+_update_basepairing = _sig("dafs_hip_update_basepairing", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
 _consensus_structure = _sig("dafs_hip_consensus_structure", C.c_int,
                             [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                              C.POINTER(C.c_float), C.c_void_p])
@@ -286,6 +289,10 @@ class Context:
     def consistency(self, w_pct_a=0.25, w_pct_s=0.25):
         check(_consistency(self._h, w_pct_a, w_pct_s))
 
+    def fourway_consistency(self, w_pct_f):
+        """DAFS::relax_fourway_consistency (-f): replaces the un-relaxed matching store and recomputes the similarity scores"""
+        check(_fourway_consistency(self._h, w_pct_f))
+
     def consistency_match(self, w_pct_a=0.25):
         check(_consistency_match(self._h, w_pct_a))
 
@@ -407,12 +414,17 @@ class Context:
         n = len(new_nodes)
         ins = (NodeInput * max(n, 1))()
         keep = []
-        for b, (s1, m1, s2, m2) in enumerate(new_nodes):
+        for b, node in enumerate(new_nodes):  # (s1, m1, s2, m2) or (s1, m1, s2, m2, p_x, p_y): supplied base-pairing matrices
+            s1, m1, s2, m2 = node[:4]
             s1 = np.ascontiguousarray(s1, np.uint32); s2 = np.ascontiguousarray(s2, np.uint32)
             m1 = np.ascontiguousarray(m1, np.uint8); m2 = np.ascontiguousarray(m2, np.uint8)
-            keep.append((s1, s2, m1, m2))
+            px = np.ascontiguousarray(node[4], np.float32) if len(node) > 4 and node[4] is not None else None
+            py = np.ascontiguousarray(node[5], np.float32) if len(node) > 5 and node[5] is not None else None
+            keep.append((s1, s2, m1, m2, px, py))
             ins[b].n1, ins[b].n2, ins[b].len1, ins[b].len2 = m1.shape[0], m2.shape[0], m1.shape[1], m2.shape[1]
             ins[b].seq1, ins[b].seq2, ins[b].mask1, ins[b].mask2 = s1.ctypes.data, s2.ctypes.data, m1.ctypes.data, m2.ctypes.data
+            ins[b].p_x = px.ctypes.data if px is not None else None
+            ins[b].p_y = py.ctypes.data if py is not None else None
         nh = np.zeros(max(n, 1), np.uint32)
         h = np.ascontiguousarray(old_handles, np.uint32)
         fo = np.zeros(max(len(h), 1), np.uint8); fn = np.zeros(max(n, 1), np.uint8)
@@ -435,6 +447,15 @@ class Context:
         r, u, p = C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(_nodes_memory(self._h, C.byref(r), C.byref(u), C.byref(p)))
         return r.value, u.value, p.value
+
+    def update_basepairing(self, seq, mask, ss):
+        """DAFS::update_basepairing_probability (--bp-update): the L x L matrix re-estimated under the structure ss"""
+        seq = np.ascontiguousarray(seq, np.uint32); mask = np.ascontiguousarray(mask, np.uint8)
+        ss = np.ascontiguousarray(ss, np.uint32)
+        n, L = mask.shape
+        p = np.zeros((L, L), np.float32)
+        check(_update_basepairing(self._h, n, L, seq.ctypes.data, mask.ctypes.data, ss.ctypes.data, p.ctypes.data))
+        return p
 
     def consensus_structure(self, seq, mask, th, want_p=False):
         seq = np.ascontiguousarray(seq, np.uint32); mask = np.ascontiguousarray(mask, np.uint8)

@@ -235,7 +235,19 @@ extern "C" int dafs_hip_set_mp(dafs_hip_ctx* c, const uint32_t* nnz, const uint3
   if ((rc = st.d_task_of_pair.upload(st.task_of_pair.data(), np, c->stream))) return rc;
   if ((rc = c->d_pair_x.upload(st.pair_x.data(), np, c->stream))) return rc;
   if ((rc = c->d_pair_y.upload(st.pair_y.data(), np, c->stream))) return rc;
-  // similarity scores
+  if ((rc = dafs_recompute_sim(c, st))) return rc;
+  st.valid = true;
+  return DAFS_HIP_OK;
+}
+
+// Similarity scores (calculate_similarity_score, dafs.cpp:713-764, :1813-1819) of every pair from the rows of a store
+// whose pairs are in row-major order (task == pair): device DP, then the host and device copies of sim.
+int dafs_recompute_sim(dafs_hip_ctx* c, dafs::mp_store& st) {
+  const uint32_t n = (uint32_t)c->len.size();
+  const uint64_t np = (uint64_t)n * (n - 1) / 2;
+  int rc;
+  if ((rc = c->d_pair_x.upload(st.pair_x.data(), np, c->stream))) return rc;
+  if ((rc = c->d_pair_y.upload(st.pair_y.data(), np, c->stream))) return rc;
   const uint32_t max_len = c->max_len();
   if ((rc = c->task_sim.reserve(np))) return rc;
   if ((rc = c->scratch.reserve(2 * ((size_t)max_len + 1) * np))) return rc;
@@ -243,16 +255,15 @@ extern "C" int dafs_hip_set_mp(dafs_hip_ctx* c, const uint32_t* nnz, const uint3
   int* row_tr = (int*)(c->scratch.ptr + ((size_t)max_len + 1) * np);
   if ((rc = mp_sim_launch(st.view(c->d_len.ptr, n), c->d_pair_x.ptr, c->d_pair_y.ptr, (uint32_t)np, c->task_sim.ptr, row_dp, row_tr, c->stream))) return rc;
   std::vector<float> ts(np);
+  if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
   if ((rc = c->task_sim.download(ts.data(), np))) return rc;
   c->sim.assign((size_t)n * n, 0.0f);
   for (uint32_t i = 0; i < n; ++i) c->sim[(size_t)i * n + i] = 1.0f;
-  for (p = 0; p < np; ++p) {
+  for (uint64_t p = 0; p < np; ++p) {
     c->sim[(size_t)st.pair_x[p] * n + st.pair_y[p]] = ts[p];
     c->sim[(size_t)st.pair_y[p] * n + st.pair_x[p]] = ts[p];
   }
-  if ((rc = c->d_sim.upload(c->sim.data(), c->sim.size(), c->stream))) return rc;
-  st.valid = true;
-  return DAFS_HIP_OK;
+  return c->d_sim.upload(c->sim.data(), c->sim.size(), c->stream);
 }
 
 // A complete matching-probability store from arrays in the layout dafs_hip_mp_fetch / dafs_hip_align_fetch write (all

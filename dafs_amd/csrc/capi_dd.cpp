@@ -388,6 +388,11 @@ int nodes_open(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const dafs_n
   uint32_t max_len = 0;
   for (uint32_t b = 0; b < nnodes; ++b) max_len = std::max(max_len, std::max(in[b].len1, in[b].len2));
   if ((rc = dd_avg_launch(ln.d_nodes->ptr, nnodes, max_len, mpv, bpv, force_wide ? 1 : 0, ln.st))) return rc;
+  for (uint32_t b = 0; b < nnodes; ++b) {  // base-pairing matrices supplied by the caller (--bp-update) replace the averages
+    const size_t XX = (size_t)in[b].len1 * in[b].len1, YY = (size_t)in[b].len2 * in[b].len2;
+    if (in[b].p_x && hip_check(hipMemcpyAsync(nodes[b].p_x, in[b].p_x, XX * 4, hipMemcpyHostToDevice, ln.st))) return DAFS_HIP_ELAUNCH;
+    if (in[b].p_y && hip_check(hipMemcpyAsync(nodes[b].p_y, in[b].p_y, YY * 4, hipMemcpyHostToDevice, ln.st))) return DAFS_HIP_ELAUNCH;
+  }
   if ((rc = ln.d_paused->reserve(nnodes))) return rc;  // doubles as the landing place of the per-node counts
   if ((rc = dd_lists_launch(ln.d_nodes->ptr, nnodes, force_wide ? 0 : max_len, dp, ln.d_paused->ptr, ln.st))) return rc;
   // ---- consensus base-pair counts -> each node's second block ----
@@ -642,11 +647,12 @@ extern "C" int dafs_hip_solve_nodes(dafs_hip_ctx* c, uint32_t nnodes, const dafs
 // Averaged base-pairing matrix of an alignment and its MEA structure: the final step of
 // DAFS::run (dafs.cpp:1857-1871) without the RNAalifold term.  p_out (len*len,
 // optional) receives the averaged matrix.
-extern "C" int dafs_hip_consensus_structure(dafs_hip_ctx* c, uint32_t n, uint32_t len, const uint32_t* seq, const uint8_t* mask,
-                                            float th, uint32_t* ss, float* score, float* p_out) {
-  if (!c || !n || !len || !seq || !mask || !ss) return DAFS_HIP_EINVAL;
+// bps: the store to average; by_row: its index is the alignment row (dafs_hip_update_basepairing) instead of the sequence.
+// decode = false stops after the average (ss / score untouched).
+static int average_and_decode(dafs_hip_ctx* c, uint32_t n, uint32_t len, const uint32_t* seq, const uint8_t* mask, const bp_store& bps, bool by_row,
+                              bool decode, float th, uint32_t* ss, float* score, float* p_out) {
+  if (!c || !n || !len || !seq || !mask || (decode && !ss)) return DAFS_HIP_EINVAL;
   if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
-  const bp_store& bps = c->bp[c->cur_bp];
   if (!bps.valid) return DAFS_HIP_EINVAL;
   geom g;
   int rc;
@@ -673,7 +679,9 @@ extern "C" int dafs_hip_consensus_structure(dafs_hip_ctx* c, uint32_t n, uint32_
     }
   }
   if (hip_check(hipMemsetAsync(nd.p_x, 0, LL * 4, c->stream))) return DAFS_HIP_ELAUNCH;
-  if (hip_check(hipMemcpyAsync((void*)nd.seq1, seq, n * 4, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
+  std::vector<uint32_t> rows(n);
+  for (uint32_t r = 0; r < n; ++r) rows[r] = by_row ? r : seq[r];
+  if (hip_check(hipMemcpyAsync((void*)nd.seq1, rows.data(), n * 4, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
   if (hip_check(hipMemcpyAsync((void*)nd.rank1, g.rank.data(), g.rank.size() * 4, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
   if (hip_check(hipMemcpyAsync((void*)nd.idx1, g.idx.data(), g.idx.size() * 4, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
   if (hip_check(hipMemcpyAsync((void*)nd.idxoff1, g.idxoff.data(), n * 4, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
@@ -681,12 +689,51 @@ extern "C" int dafs_hip_consensus_structure(dafs_hip_ctx* c, uint32_t n, uint32_
   mp_store_dev none;
   memset(&none, 0, sizeof none);
   if ((rc = dd_avg_launch(c->d_nodes.ptr, 1, len, none, bps.view(), 0, c->stream))) return rc;
-  if ((rc = nussinov_launch(len, nd.p_x, nullptr, 0.0f, th, nd.wx, d_ss, nd.score, c->stream))) return rc;
   float s = 0;
-  if (hip_check(hipMemcpyAsync(ss, d_ss, (size_t)len * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
-  if (hip_check(hipMemcpyAsync(&s, nd.score, 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+  if (decode) {
+    if ((rc = nussinov_launch(len, nd.p_x, nullptr, 0.0f, th, nd.wx, d_ss, nd.score, c->stream))) return rc;
+    if (hip_check(hipMemcpyAsync(ss, d_ss, (size_t)len * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+    if (hip_check(hipMemcpyAsync(&s, nd.score, 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+  }
   if (p_out && hip_check(hipMemcpyAsync(p_out, nd.p_x, LL * 4, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
   if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
   if (score) *score = s;
   return DAFS_HIP_OK;
+}
+
+extern "C" int dafs_hip_consensus_structure(dafs_hip_ctx* c, uint32_t n, uint32_t len, const uint32_t* seq, const uint8_t* mask,
+                                            float th, uint32_t* ss, float* score, float* p_out) {
+  if (!c) return DAFS_HIP_EINVAL;
+  return average_and_decode(c, n, len, seq, mask, c->bp[c->cur_bp], false, true, th, ss, score, p_out);
+}
+
+// DAFS::update_basepairing_probability (dafs.cpp:609-712, options --bp-update / --bp-update1; no RNAalifold term, one level
+// of brackets): every sequence of the alignment is folded again under the constraint that the common structure ss puts on
+// it -- paired columns whose two residues exist in the row become '(' and ')', everything else stays free -- and the
+// constrained posteriors (> CUTOFF) are averaged over the rows like the unconstrained ones, cut off at CUTOFF.
+// The constraint strings are host work (index mapping); the folds run as one batch, the average on the device.
+extern "C" int dafs_hip_update_basepairing(dafs_hip_ctx* c, uint32_t n, uint32_t len, const uint32_t* seq, const uint8_t* mask,
+                                           const uint32_t* ss, float* p_out) {
+  if (!c || !n || !len || !seq || !mask || !ss || !p_out) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  std::vector<char> str((size_t)len + 1);
+  dafs_hip_make_brackets(len, ss, str.data());
+  std::vector<std::string> cons(n);
+  std::vector<uint32_t> rev(len);
+  for (uint32_t r = 0; r < n; ++r) {
+    if (seq[r] >= c->len.size()) return DAFS_HIP_EINVAL;
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < len; ++i) rev[i] = mask[(size_t)r * len + i] ? k++ : DAFS_HIP_NONE;
+    if (k != c->len[seq[r]]) return DAFS_HIP_EINVAL;
+    std::string& con = cons[r];
+    con.assign(k, '?');
+    for (uint32_t i = 0; i < len; ++i)
+      if (ss[i] != DAFS_HIP_NONE && ss[i] < len && rev[i] != DAFS_HIP_NONE && rev[ss[i]] != DAFS_HIP_NONE) {  // :640-652
+        if (str[i] == '(') { con[rev[i]] = '('; con[rev[ss[i]]] = ')'; }
+        else { con[rev[i]] = '.'; con[rev[ss[i]]] = '.'; }
+      }
+  }
+  int rc = dafs_fold_rows_constrained(c, n, seq, cons, 0.01f, c->bp_rows);  // CONTRAfold(CUTOFF), dafs.cpp:1704
+  if (rc) return rc;
+  return average_and_decode(c, n, len, seq, mask, c->bp_rows, true, false, 0.0f, nullptr, nullptr, p_out);
 }

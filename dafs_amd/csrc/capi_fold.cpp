@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "../../include/dafs_hip.h"
@@ -205,6 +206,53 @@ extern "C" int dafs_hip_fold_posteriors_end(dafs_hip_ctx* c) {
 extern "C" int dafs_hip_fold_posteriors(dafs_hip_ctx* c, int model, float th) {
   const int rc = dafs_hip_fold_posteriors_begin(c, model, th);
   return rc ? rc : dafs_hip_fold_posteriors_end(c);
+}
+
+// Constrained posteriors of the rows of one alignment (DAFS::update_basepairing_probability, dafs.cpp:657-663: one
+// s_model_->calculate(seq, con, bp) per sequence), as one batch; the result is a store whose index is the row.
+int dafs_fold_rows_constrained(dafs_hip_ctx* c, uint32_t n, const uint32_t* seq, const std::vector<std::string>& cons, float th, dafs::bp_store& st) {
+  if (!c || !n || !seq || cons.size() != n || c->fold_pending) return DAFS_HIP_EINVAL;
+  st.valid = false;
+  fold_job job;
+  std::vector<int> maps, one;
+  std::vector<uint64_t> rp_off(n + 1, 0);
+  uint64_t residues = 0;
+  for (uint32_t r = 0; r < n; ++r) {
+    if (seq[r] >= c->len.size()) return DAFS_HIP_EINVAL;
+    const uint32_t L = c->len[seq[r]];
+    if (cons[r].size() < L) return DAFS_HIP_EINVAL;
+    int rc = parse_constraint(cons[r].c_str(), L, one);
+    if (rc) return rc;
+    job.add(L, c->off[seq[r]], true, (uint32_t)maps.size());
+    maps.insert(maps.end(), one.begin(), one.end());
+    rp_off[r + 1] = rp_off[r] + L + 1;
+    residues += L;
+  }
+  int rc;
+  if ((rc = c->cf_cons.upload(maps.data(), maps.size(), c->stream))) return rc;
+  cf_batch B;
+  if ((rc = run_job(c, job, c->codes.ptr, c->cf_cons.ptr, &B, c->stream))) return rc;
+  if ((rc = st.rowptr.reserve(rp_off[n]))) return rc;
+  if ((rc = st.nnz.reserve(n))) return rc;
+  if ((rc = st.bp_off.reserve(n + 1))) return rc;
+  if ((rc = st.rp_off.upload(rp_off.data(), n + 1, c->stream))) return rc;
+  if ((rc = c->counters.reserve(4))) return rc;
+  uint64_t cap = 8ull * residues + 1024;
+  for (int attempt = 0;; ++attempt) {
+    if ((rc = st.col.reserve(cap))) return rc;
+    if ((rc = st.val.reserve(cap))) return rc;
+    if (hip_check(hipMemsetAsync(c->counters.ptr, 0, 4 * sizeof(unsigned long long), c->stream))) return DAFS_HIP_ELAUNCH;
+    if ((rc = bp_compact_launch(B, n, th, st.rp_off.ptr, st.rowptr.ptr, st.col.ptr, st.val.ptr, st.bp_off.ptr, st.nnz.ptr,
+                                c->counters.ptr, cap, (int*)(c->counters.ptr + 2), c->stream)))
+      return rc;
+    unsigned long long h[4];
+    if (hip_check(hipMemcpyAsync(h, c->counters.ptr, sizeof h, hipMemcpyDeviceToHost, c->stream))) return DAFS_HIP_ELAUNCH;
+    if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
+    const int status = (int)(h[2] & 0xffffffffu);
+    if (status == 0) { st.total_nnz = h[0]; st.valid = true; return DAFS_HIP_OK; }
+    if (status != DAFS_HIP_EOVERFLOW || attempt >= 4) return status;
+    cap = std::max<uint64_t>(h[0], cap * 2);
+  }
 }
 
 // Single-sequence plugin call: CONTRAfold<float>::ComputePosterior (reference

@@ -80,13 +80,17 @@ extern "C" int dafs_hip_bp_fetch(dafs_hip_ctx* c, int relaxed, uint32_t* rowptr,
 // stores (dafs.cpp:1822-1827).  A weight of 0 skips that transform, as the reference does.
 // which: bit 0 the base-pairing transform, bit 1 the matching transform (the two read only un-relaxed stores, so they
 // may be run in either order, e.g. the matching transform while the folding kernels are still busy)
-static int consistency_parts(dafs_hip_ctx* c, float w_pct_a, float w_pct_s, int which, uint64_t pair_begin = 0, uint64_t pair_end = 0) {
+// fourway: the matching part runs DAFS::relax_fourway_consistency (weight w_pct_a) instead, and its result becomes the
+// un-relaxed store (dafs_hip_fourway_consistency below)
+static int consistency_parts(dafs_hip_ctx* c, float w_pct_a, float w_pct_s, int which, uint64_t pair_begin = 0, uint64_t pair_end = 0,
+                             bool fourway = false) {
   if (!c || c->len.empty()) return DAFS_HIP_EINVAL;
   if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
   const uint32_t n = (uint32_t)c->len.size();
   const uint64_t all = (uint64_t)n * (n - 1) / 2;
   mp_store& raw = c->mp[0];
-  if (!raw.valid || raw.n_tasks != all || c->sim.empty()) return DAFS_HIP_EINVAL;
+  if (!raw.valid || raw.n_tasks != all || (c->sim.empty() && !fourway)) return DAFS_HIP_EINVAL;
+  if (fourway && !c->bp[0].valid) return DAFS_HIP_EINVAL;
   const uint32_t max_len = c->max_len();
   const mp_store_dev mpv = raw.view(c->d_len.ptr, n);
   int rc;
@@ -174,6 +178,7 @@ static int consistency_parts(dafs_hip_ctx* c, float w_pct_a, float w_pct_s, int 
       a.rp_off = out.rp_off.ptr; a.rowptr_pool = out.rowptr_pool.ptr; a.col = out.col.ptr; a.val = out.val.ptr;
       a.pool_top = c->counters.ptr; a.pool_cap = cap; a.pair_off = out.pair_off.ptr; a.pair_nnz = out.pair_nnz.ptr;
       a.status = (int*)(c->counters.ptr + 2);
+      if (fourway) { a.bp = c->bp[0].view(); a.w_f = w_pct_a; }
       // dense row tiles, in batches of at most kTileFloats; the tile memory is the pair kernels' scratch
       const uint64_t kTileFloats = 1ull << 31;  // 8 GiB
       for (uint64_t p0 = pair_begin; p0 < pair_end;) {
@@ -193,7 +198,8 @@ static int consistency_parts(dafs_hip_ctx* c, float w_pct_a, float w_pct_s, int 
         if (hip_check(hipMemcpyAsync(c->work.ptr, toff.data(), cnt * 8, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
         if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;  // toff dies at the end of the scope
         a.tile = c->scratch.ptr; a.tile_off = (const uint64_t*)c->work.ptr; a.sum_w = (float*)c->work2.ptr;
-        if ((rc = pct_match_launch(a, max_len, (uint32_t)p0, (uint32_t)cnt, c->stream))) return rc;
+        if ((rc = fourway ? pct_fourway_launch(a, max_len, (uint32_t)p0, (uint32_t)cnt, c->stream)
+                          : pct_match_launch(a, max_len, (uint32_t)p0, (uint32_t)cnt, c->stream))) return rc;
         p0 = p1;
       }
       unsigned long long h[4];
@@ -207,6 +213,19 @@ static int consistency_parts(dafs_hip_ctx* c, float w_pct_a, float w_pct_s, int 
     c->cur_mp = 1;
   }
   return DAFS_HIP_OK;
+}
+
+// DAFS::relax_fourway_consistency (dafs.cpp:377-444, called at :1808-1809 when -f is not 0): mp_ is replaced by its mix with
+// the stacking evidence of the base-pairing matrices, BEFORE the similarity scores are taken -- so the result becomes the
+// context's un-relaxed store and the scores are recomputed from it.  Needs the un-relaxed base-pairing store.
+extern "C" int dafs_hip_fourway_consistency(dafs_hip_ctx* c, float w_pct_f) {
+  if (w_pct_f == 0.0f) return DAFS_HIP_OK;
+  int rc = consistency_parts(c, w_pct_f, 0.0f, 2, 0, 0, true);
+  if (rc) return rc;
+  std::swap(c->mp[0], c->mp[1]);
+  c->mp[1].valid = false;
+  c->cur_mp = 0;
+  return dafs_recompute_sim(c, c->mp[0]);
 }
 
 extern "C" int dafs_hip_consistency(dafs_hip_ctx* c, float w_pct_a, float w_pct_s) { return consistency_parts(c, w_pct_a, w_pct_s, 3); }

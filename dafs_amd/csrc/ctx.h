@@ -111,6 +111,7 @@ struct dafs_hip_ctx {
   // stores: [0] as computed by the models, [1] after the consistency transforms
   dafs::mp_store mp[2];
   dafs::bp_store bp[2];
+  dafs::bp_store bp_rows;  // dafs_hip_update_basepairing: constrained posteriors of the rows of one alignment (store index = row)
   int cur_mp = 0, cur_bp = 0;
   // similarity matrix (host copy + device dense N*N)
   std::vector<float> sim;
@@ -217,5 +218,12 @@ struct dafs_hip_ctx {
     for (int k = 0; k < 2; ++k) { if (h_paused[k]) (void)hipHostFree(h_paused[k]); h_paused[k] = nullptr; h_paused_cap[k] = 0; }
     d_cf_params.release(); cf_seqs.release(); cf_codes.release(); cf_iws.release(); cf_cons.release(); cf_fws.release(); cf_post.release(); cf_logz.release();
     for (int k = 0; k < 2; ++k) { mp[k].release(); bp[k].release(); }
+    bp_rows.release();
   }
 };
+
+// capi_align.cpp: similarity scores of all pairs from the rows of a store in row-major pair order (host + device sim)
+int dafs_recompute_sim(dafs_hip_ctx* c, dafs::mp_store& st);
+// capi_fold.cpp: CONTRAfold posteriors of the context's sequences seq[0..n) under constraint strings ("?.()", one per row),
+// compacted with threshold th into `out`, whose "sequence" index is the row (Fold::Model::calculate(seq, str, bp), fold.cpp:191-207)
+int dafs_fold_rows_constrained(dafs_hip_ctx* c, uint32_t n, const uint32_t* seq, const std::vector<std::string>& cons, float th, dafs::bp_store& out);

@@ -11,7 +11,6 @@
 //   -s Boltzmann / -s Vienna and the RNAalifold term need ViennaRNA arithmetic: not available.
 //      The default fold model here is CONTRAfold; asking for the others is an error.
 //   --fold-decoder IPknot / --ipknot / -m 0 need an ILP solver: not available.
-//   -f (four-way PCT) other than 0: not implemented.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -65,7 +64,7 @@ const char* kHelp =
     "  -w, --weight arg      Weight of the expected accuracy score for secondary structures (default: 4.0)\n"
     "      --eta arg         Initial step width for the subgradient optimization (default: 0.5)\n"
     "  -m, --max-iter T      The maximum number of iteration of the subgradient optimization (default: 600)\n"
-    "  -f, --fourway-pct arg Weight of four-way PCT (default: 0.0; other values are not supported)\n"
+    "  -f, --fourway-pct arg Weight of four-way PCT (default: 0.0)\n"
     "  -v, --verbose arg     The level of verbose outputs (default: 0)\n"
     "      --device N        HIP device index (default: 0)\n"
     "\n Aligning options:\n"
@@ -83,6 +82,8 @@ const char* kHelp =
     "      --no-alifold      No use of RNAalifold (always the case in this build)\n"
     "  -T, --fold-th1 arg    Threshold for base-pairing probabilities of the conclusive common secondary structures\n"
     "  -G, --gamma1 arg      ... specified by 1/(gamma+1)\n"
+    "      --bp-update       Re-estimate the base-pairing matrices of the last alignment step under the predicted structure\n"
+    "      --bp-update1      The same for the conclusive common secondary structure\n"
     "      --fold-aux FILENAME        Load base-pairing probability matrices from FILENAME\n"
     "      --save-fold-aux FILENAME   Write base-pairing probability matrices in the --fold-aux format\n";
 
@@ -232,8 +233,19 @@ void project_alignment(ALN& aln, const ALN& a1, const ALN& a2, const VU& z) {
 struct NodeJob {  // flattened child alignments of one node, kept alive across the C call
   std::vector<uint32_t> s1, s2;
   std::vector<uint8_t> m1, m2;
+  std::vector<float> px, py;  // --bp-update: re-estimated base-pairing matrices
   VU x, y, z;
 };
+
+// the `if (use_bp_update_)` blocks of align_alignments(ss, ...), :919-934, and of DAFS::run, :1863-1869: decode the averaged
+// matrix, re-estimate it under that structure (update_basepairing_probability, :609-712)
+void updated_bp(dafs_hip_ctx* ctx, uint32_t n, uint32_t len, const std::vector<uint32_t>& seq, const std::vector<uint8_t>& mask, float th,
+                std::vector<float>& p) {
+  VU ss(len);
+  check(dafs_hip_consensus_structure(ctx, n, len, seq.data(), mask.data(), th, ss.data(), nullptr, nullptr));
+  p.resize((size_t)len * len);
+  check(dafs_hip_update_basepairing(ctx, n, len, seq.data(), mask.data(), ss.data(), p.data()));
+}
 void flatten(const ALN& a, std::vector<uint32_t>& s, std::vector<uint8_t>& m) {
   const size_t L = a[0].second.size();
   s.resize(a.size());
@@ -246,7 +258,7 @@ void flatten(const ALN& a, std::vector<uint32_t>& s, std::vector<uint8_t>& m) {
 
 // align_alignments for a batch of independent (aln1, aln2) pairs: :896-981
 std::vector<float> solve_batch(dafs_hip_ctx* ctx, const dafs_dd_params& prm, const std::vector<const ALN*>& a1,
-                               const std::vector<const ALN*>& a2, std::vector<ALN>& out, int verbose) {
+                               const std::vector<const ALN*>& a2, std::vector<ALN>& out, int verbose, bool bp_update) {
   const size_t nb = a1.size();
   std::vector<NodeJob> jobs(nb);
   std::vector<dafs_node_input> in(nb);
@@ -261,6 +273,12 @@ std::vector<float> solve_batch(dafs_hip_ctx* ctx, const dafs_dd_params& prm, con
     j.x.resize(in[b].len1); j.y.resize(in[b].len2); j.z.resize(in[b].len1);
     res[b].x = j.x.data(); res[b].y = j.y.data(); res[b].z = j.z.data();
   }
+  if (bp_update)
+    for (size_t b = 0; b < nb; ++b) {  // refine() goes through align_alignments(ss, ...) too
+      updated_bp(ctx, in[b].n1, in[b].len1, jobs[b].s1, jobs[b].m1, prm.th_s, jobs[b].px);
+      updated_bp(ctx, in[b].n2, in[b].len2, jobs[b].s2, jobs[b].m2, prm.th_s, jobs[b].py);
+      in[b].p_x = jobs[b].px.data(); in[b].p_y = jobs[b].py.data();
+    }
   check(dafs_hip_solve_nodes(ctx, (uint32_t)nb, in.data(), &prm, res.data()));
   std::vector<float> score(nb);
   out.resize(nb);
@@ -415,9 +433,8 @@ int run(const Options& o) {
     if (o.fold_model != "CONTRAfold") throw "Unknown folding model: " + o.fold_model;
   }
   if (o.fold_decoder != "Nussinov" || o.ipknot) throw "Folding decoder IPknot needs an ILP solver, which this build does not contain";
-  if (o.fourway != 0.0f) throw "four-way PCT (-f) is not supported by this build";
   if (o.max_iter <= 0) throw "-m 0 (exact ILP) needs an ILP solver, which this build does not contain";
-  if (o.bp_update || o.bp_update1) throw "--bp-update / --bp-update1 are not supported by this build";
+  if ((o.bp_update || o.bp_update1) && !o.fold_aux.empty()) throw "--bp-update / --bp-update1 need a folding model (-s CONTRAfold), not --fold-aux";
   if (o.verbose >= 1) {
     if (!o.no_alifold) std::cerr << "note: RNAalifold is not available in this build; running as with --no-alifold" << std::endl;
     if (!o.fold_model_given && o.fold_aux.empty()) std::cerr << "note: default folding model is CONTRAfold in this build" << std::endl;
@@ -448,9 +465,10 @@ int run(const Options& o) {
     check(dafs_hip_fold_posteriors_begin(ctx, DAFS_FOLD_CONTRAFOLD, kCutoff));
     folding = true;
   }
+  bool fold_saved = false;
   auto finish_folding = [&]() {
     if (folding) { check(dafs_hip_fold_posteriors_end(ctx)); folding = false; }
-    if (!o.save_fold_aux.empty()) save_fold_aux(ctx, o.save_fold_aux, fa);
+    if (!o.save_fold_aux.empty() && !fold_saved) { save_fold_aux(ctx, o.save_fold_aux, fa); fold_saved = true; }
   };
 
   std::vector<node_t> tree(1, std::make_pair(0.0f, std::make_pair(-1u, -1u)));
@@ -460,6 +478,10 @@ int run(const Options& o) {
     if (!o.align_aux.empty()) load_align_aux(ctx, o.align_aux, fa);
     else check(dafs_hip_align_posteriors(ctx, align_model, o.align_th, 0, 0));
     if (!o.save_align_aux.empty()) save_align_aux(ctx, o.save_align_aux, fa);
+    if (o.fourway != 0.0f) {  // relax_fourway_consistency (:1808-1809): needs the base-pairing rows, replaces mp_ before sim_
+      finish_folding();
+      check(dafs_hip_fourway_consistency(ctx, o.fourway));
+    }
     std::vector<float> sim((size_t)N * N);
     check(dafs_hip_get_sim(ctx, sim.data()));
     check(dafs_hip_consistency_match(ctx, o.align_pct));
@@ -517,6 +539,15 @@ int run(const Options& o) {
         in[b].len1 = (uint32_t)a1[0].second.size(); in[b].len2 = (uint32_t)a2[0].second.size();
         in[b].seq1 = j.s1.data(); in[b].seq2 = j.s2.data(); in[b].mask1 = j.m1.data(); in[b].mask2 = j.m2.data();
         j.x.resize(in[b].len1); j.y.resize(in[b].len2); j.z.resize(in[b].len1);
+        if (o.bp_update && ready[b] == tree.size() - 1) {
+          // the top call of the recursion re-estimates both base-pairing matrices under the structure decoded from
+          // their averages (align_alignments(ss, ...), :919-934)
+          j.px.resize((size_t)in[b].len1 * in[b].len1);
+          j.py.resize((size_t)in[b].len2 * in[b].len2);
+          updated_bp(ctx, in[b].n1, in[b].len1, j.s1, j.m1, prm.th_s, j.px);
+          updated_bp(ctx, in[b].n2, in[b].len2, j.s2, j.m2, prm.th_s, j.py);
+          in[b].p_x = j.px.data(); in[b].p_y = j.py.data();
+        }
       }
       std::vector<uint32_t> old_handles(n_old ? n_old : 1), new_handles(ready.size() ? ready.size() : 1);
       std::vector<uint8_t> fin(open.size() ? open.size() : 1, 0);
@@ -569,7 +600,7 @@ int run(const Options& o) {
       }
     }
     std::vector<ALN> merged;
-    const std::vector<float> sc = solve_batch(ctx, prm, {&part[0]}, {&part[1]}, merged, o.verbose);
+    const std::vector<float> sc = solve_batch(ctx, prm, {&part[0]}, {&part[1]}, merged, o.verbose, o.bp_update);
     if (sc[0] > s) { s = sc[0]; root.swap(merged[0]); }
   }
 
@@ -582,6 +613,11 @@ int run(const Options& o) {
     const uint32_t L = (uint32_t)root[0].second.size();
     VU ss(L);
     check(dafs_hip_consensus_structure(ctx, (uint32_t)root.size(), L, rs.data(), rm.data(), o.fold_th1[0], ss.data(), nullptr, nullptr));
+    if (o.bp_update1) {  // :1863-1869: re-estimate under the decoded structure, decode again (SparseNussinov::decode(p, ss, str))
+      std::vector<float> p((size_t)L * L);
+      check(dafs_hip_update_basepairing(ctx, (uint32_t)root.size(), L, rs.data(), rm.data(), ss.data(), p.data()));
+      check(dafs_hip_nussinov_decode(ctx, o.fold_th1[0], 0.0f, L, p.data(), nullptr, ss.data(), nullptr));
+    }
     std::vector<char> buf(L + 1);
     dafs_hip_make_brackets(L, ss.data(), buf.data());
     str.assign(buf.data());

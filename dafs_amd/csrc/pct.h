@@ -28,6 +28,9 @@ struct pct_match_args {
   const uint64_t* tile_off;
   float* sum_w;           // per pair of the launch: sum of the weights w_z (written by the row kernel)
   uint32_t max_len;       // filled by the launcher
+  // four-way transform only (pct_fourway_launch): the un-relaxed base-pairing store and the weight -f
+  bp_store_dev bp;
+  float w_f;
 };
 
 struct pct_bp_args {
@@ -53,6 +56,8 @@ struct pct_bp_args {
 
 int pct_match_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint32_t count, hipStream_t st);
 int pct_bp_launch(pct_bp_args a, uint32_t max_len, hipStream_t st);
+// DAFS::relax_fourway_consistency (dafs.cpp:377-444) for the pairs [pair0, pair0 + count): same outputs as pct_match_launch
+int pct_fourway_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint32_t count, hipStream_t st);
 // similarity scores of all pairs from a stored matching-probability set; row_dp / row_tr: (max_len + 1) * npairs words each
 int mp_sim_launch(mp_store_dev in, const uint32_t* pair_x, const uint32_t* pair_y, uint32_t npairs, float* task_sim, float* row_dp, int* row_tr,
                   hipStream_t st);

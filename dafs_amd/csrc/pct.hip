@@ -589,6 +589,82 @@ size_t pct_rows_lds_bytes(uint32_t nseq, uint32_t row_cap) {
 }
 
 // pairs [pair0, pair0 + count) whose tiles (a.tile, a.tile_off, a.sum_w) have been laid out by the caller
+// ---------------------------------------------------------------------------------------------
+// DAFS::relax_fourway_consistency, reference src/dafs.cpp:377-444 (option -f): every entry (a, b) of mp[x][y] becomes
+//   p_ab (1 - w)  +  w * sum over base pairs (a, j) of x, (b, l) of y with (j, l) in mp[x][y] of  p_aj p_bl p_jl
+//                 +  w * sum over base pairs (i, a) of x, (k, b) of y with (i, k) in mp[x][y] of  p_ia p_kb p_ik
+// The reference scatters the last sum from the rows i < a while it walks them, so cell (a, b) receives it first, in
+// the order (i ascending, k ascending), then its own base term (a double product added to the float cell), then the
+// middle sum in the order (j ascending, l ascending) -- the order a thread per entry reproduces here by gathering.
+// Cells that are not entries of mp[x][y] stay 0.  One workgroup per pair writes the dense L1 x L2 tile that k_pct_emit
+// turns into rows, transposed rows and counts (its division by sum_w = 1 is exact).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fourway_rows(pct_match_args a, uint32_t pair0) {
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t p = pair0 + blockIdx.x;
+  const uint32_t x = a.pair_x[p], y = a.pair_y[p];
+  const uint32_t L1 = a.in.len[x], L2 = a.in.len[y];
+  float* tile = a.tile + a.tile_off[blockIdx.x];
+  for (size_t c = tid; c < (size_t)L1 * L2; c += nt) tile[c] = 0.0f;
+  if (tid == 0) a.sum_w[blockIdx.x] = 1.0f;
+  __syncthreads();
+  const float w = a.w_f;
+  const uint32_t t = a.in.task_of_pair[pair_id(x, y, a.in.nseq)];
+  const uint32_t* rp = a.in.rowptr_pool + a.in.rp_off[t];  // row pointers of mp[x][y]
+  const uint32_t nnz = a.in.pair_nnz[t];
+  const uint32_t* mcol = a.in.col + a.in.pair_off[t];
+  const float* mval = a.in.val + a.in.pair_off[t];
+  for (uint32_t e = tid; e < nnz; e += nt) {
+    uint32_t lo = 0, hi = L1;  // row of entry e: the largest r with rp[r] <= e
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rp[mid] <= e) lo = mid; else hi = mid; }
+    const uint32_t ra = lo, cb = mcol[e];
+    const float p_ab = mval[e];
+    float post = 0.0f;
+    // what the rows i < a delivered: base pairs (i, a) of x in the order of i, then the entries (i, k) of that row
+    for (uint32_t i = 0; i < ra; ++i) {
+      const row_ref bi = bp_row(a.bp, x, i);
+      float p_ia = 0.0f;
+      bool has = false;
+      for (uint32_t q = 0; q < bi.n; ++q)
+        if (bi.col[q] == ra) { p_ia = bi.val[q]; has = true; }
+      if (!has) continue;
+      for (uint32_t q = rp[i]; q < rp[i + 1]; ++q) {
+        const uint32_t k = mcol[q];
+        const float p_ik = mval[q];
+        const row_ref bk = bp_row(a.bp, y, k);
+        for (uint32_t r = 0; r < bk.n; ++r)
+          if (bk.col[r] == cb) post += p_ia * bk.val[r] * p_ik * w;  // :414
+      }
+    }
+    post = (float)((double)post + (double)p_ab * (1.0 - (double)w));  // :397
+    {
+      const row_ref ba = bp_row(a.bp, x, ra);
+      const row_ref bb = bp_row(a.bp, y, cb);
+      for (uint32_t q = 0; q < ba.n; ++q) {
+        const uint32_t j = ba.col[q];
+        const float p_aj = ba.val[q];
+        uint32_t l1 = rp[j], e1 = rp[j + 1], l2 = 0;
+        while (l1 != e1 && l2 != bb.n) {  // :402-419
+          const uint32_t c1 = mcol[l1], c2 = bb.col[l2];
+          if (c1 < c2) ++l1;
+          else if (c1 > c2) ++l2;
+          else { post += p_aj * bb.val[l2] * mval[l1] * w; ++l1; ++l2; }  // :413
+        }
+      }
+    }
+    tile[(size_t)ra * L2 + cb] = post;
+  }
+}
+
+int pct_fourway_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint32_t count, hipStream_t st) {
+  if (!count) return DAFS_HIP_OK;
+  a.max_len = max_len;
+  hipLaunchKernelGGL(k_fourway_rows, dim3(count), dim3(256), 0, st, a, pair0);
+  if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
+  hipLaunchKernelGGL(k_pct_emit, dim3(count), dim3(256), (size_t)2 * (max_len + 2) * 4, st, a, pair0);
+  return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
+}
+
 int pct_match_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint32_t count, hipStream_t st) {
   if (!count) return DAFS_HIP_OK;
   // The four rows a wavefront accumulates sit row_cap + 68 words apart in LDS, and the two rows of a 32-lane half

@@ -88,7 +88,7 @@ class Result:
 
 def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25, w_pct_s=0.25, th_a=0.01,
         th_s=0.2, th_s1=None, align_model=capi.ALIGN_PROBCONS, force_iters=0, timers=None, level_sync=False, slice_iters=None,
-        mp=None, skip_uncoupled_folds=True, shard=None, round_us=None):
+        mp=None, skip_uncoupled_folds=True, shard=None, round_us=None, w_pct_f=0.0, bp_update=False, bp_update1=False):
     """The whole run.  bp: per-sequence (rowptr, col, val) base-pairing rows (--fold-aux); None
     computes them with the device fold model.  mp: supplied matching probabilities (--align-aux), see Context.set_mp.
     shard: (torch.distributed module, torch device) of an initialised process group -- phase 1 (folds, pair posteriors,
@@ -106,14 +106,14 @@ def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25
         t += [time.perf_counter()] * 2
         sim = ctx.sim()
     else:
-        sim = _phase1_local(ctx, seqs, bp, mp, align_model, th_a, w_pct_a, w_pct_s, t)
+        sim = _phase1_local(ctx, seqs, bp, mp, align_model, th_a, w_pct_a, w_pct_s, t, w_pct_f)
     score, left, right = capi.build_tree(sim)  # same code as the command line (build_tree below is its Python twin, kept for the CPU tests)
     t.append(time.perf_counter())
     return _phase2(ctx, own, names, seqs, n, sim, score, left, right, t, w, eta0, t_max, th_a, th_s, th_s1, force_iters, level_sync, slice_iters,
-                   skip_uncoupled_folds, round_us)
+                   skip_uncoupled_folds, round_us, bp_update, bp_update1)
 
 
-def _phase1_local(ctx, seqs, bp, mp, align_model, th_a, w_pct_a, w_pct_s, t):
+def _phase1_local(ctx, seqs, bp, mp, align_model, th_a, w_pct_a, w_pct_s, t, w_pct_f=0.0):
     import time
     ctx.set_sequences(seqs)
     # The folding (one workgroup per sequence) leaves most of the device idle, and nothing before the base-pair
@@ -129,16 +129,22 @@ def _phase1_local(ctx, seqs, bp, mp, align_model, th_a, w_pct_a, w_pct_s, t):
     else:
         ctx.align_posteriors(align_model, th_a, fetch=False)
     t.append(time.perf_counter())
+    folded = bp is not None
+    if w_pct_f != 0.0:  # relax_fourway_consistency (dafs.cpp:1808): needs the base-pairing rows, replaces mp_ before sim_
+        if not folded:
+            ctx.fold_end()
+            folded = True
+        ctx.fourway_consistency(w_pct_f)
     sim = ctx.sim()
     ctx.consistency_match(w_pct_a)
-    if bp is None:
+    if not folded:
         ctx.fold_end()
     ctx.consistency_bp(w_pct_s)
     return sim
 
 
 def _phase2(ctx, own, names, seqs, n, sim, score, left, right, t, w, eta0, t_max, th_a, th_s, th_s1, force_iters, level_sync, slice_iters,
-            skip_uncoupled_folds, round_us=None):
+            skip_uncoupled_folds, round_us=None, bp_update=False, bp_update1=False):
     import time
     res = Result()
     res.sim = sim
@@ -185,7 +191,18 @@ def _phase2(ctx, own, names, seqs, n, sim, score, left, right, t, w, eta0, t_max
             pending = [i for i in pending if i not in ready]
             ids = sorted(open_nodes)
             t_round = time.perf_counter()
-            hs, dims, fin_old, fin_new = ctx.nodes_round([(aln[left[i]][0], aln[left[i]][1], aln[right[i]][0], aln[right[i]][1]) for i in ready],
+            def node_input(i):
+                a1, a2 = aln[left[i]], aln[right[i]]
+                if bp_update and i == 2 * n - 2:
+                    # --bp-update: the top call of the recursion (DAFS::align(ss, aln, root), dafs.cpp:1518-1537) re-estimates
+                    # both base-pairing matrices under the structure decoded from their averages (:919-934)
+                    upd = []
+                    for s_idx, msk in (a1, a2):
+                        _, ss0, _ = ctx.consensus_structure(s_idx, msk, th_s)
+                        upd.append(ctx.update_basepairing(s_idx, msk, ss0))
+                    return (a1[0], a1[1], a2[0], a2[1], upd[0], upd[1])
+                return (a1[0], a1[1], a2[0], a2[1])
+            hs, dims, fin_old, fin_new = ctx.nodes_round([node_input(i) for i in ready],
                                                          [open_nodes[i][0] for i in ids], prm, slice_iters or 0, round_us or 0)
             for i, h, d in zip(ready, hs, dims):
                 open_nodes[i] = (h, d[0], d[1])
@@ -205,7 +222,10 @@ def _phase2(ctx, own, names, seqs, n, sim, score, left, right, t, w, eta0, t_max
     root = 2 * n - 2
     sidx, mask = aln[root]
     t.append(time.perf_counter())
-    _, ss, _ = ctx.consensus_structure(sidx, mask, th_s if th_s1 is None else th_s1)
+    th1 = th_s if th_s1 is None else th_s1
+    _, ss, _ = ctx.consensus_structure(sidx, mask, th1)
+    if bp_update1:  # :1863-1869: decode, re-estimate under that structure, decode again
+        _, ss = ctx.nussinov(ctx.update_basepairing(sidx, mask, ss), None, th1)
     res.ss = ss
     res.ss_str = capi.make_brackets(ss)
     order = np.argsort(sidx, kind="stable")  # std::sort(aln) :1876

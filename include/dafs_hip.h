@@ -231,6 +231,11 @@ int dafs_hip_consistency(dafs_hip_ctx* ctx, float w_pct_a, float w_pct_s);
 /* the two transforms separately (each reads un-relaxed stores only) */
 int dafs_hip_consistency_match(dafs_hip_ctx* ctx, float w_pct_a);
 int dafs_hip_consistency_bp(dafs_hip_ctx* ctx, float w_pct_s);
+/* DAFS::relax_fourway_consistency (src/dafs.cpp:377-444; option -f, called at :1808-1809 between the alignment model and
+ * the similarity scores): the un-relaxed matching store is replaced by its mix with the stacking evidence of the un-relaxed
+ * base-pairing store (dafs_hip_fold_posteriors / dafs_hip_set_bp must have run), and the similarity scores are recomputed
+ * from the result.  Call before dafs_hip_get_sim / dafs_hip_consistency*.  w_pct_f = 0 does nothing, like the reference. */
+int dafs_hip_fourway_consistency(dafs_hip_ctx* ctx, float w_pct_f);
 /* relax_matching_probability for the output pairs [pair_begin, pair_end) of the row-major pair enumeration only (every
  * output pair is independent of the others, src/dafs.cpp:265-315): the shard of one rank of a multi-GPU run.  The
  * other pairs of the relaxed store stay empty until the gathered whole is installed with dafs_hip_mp_install. */
@@ -276,6 +281,9 @@ typedef struct {
   const uint32_t* seq2;   /* [n2]                                                             */
   const uint8_t* mask1;   /* [n1*len1] 1 = residue, 0 = gap (the reference's vector<bool>)    */
   const uint8_t* mask2;   /* [n2*len2]                                                        */
+  const float* p_x;       /* optional [len1*len1]: base-pairing matrix of alignment 1 to use in   */
+  const float* p_y;       /* optional [len2*len2]  place of the averaged one (--bp-update: the matrices
+                             re-estimated by dafs_hip_update_basepairing, dafs.cpp:919-934); NULL = average */
 } dafs_node_input;
 
 typedef struct {
@@ -326,6 +334,13 @@ int dafs_hip_nodes_memory(dafs_hip_ctx* ctx, uint64_t* reserved, uint64_t* in_us
  * averaged base-pairing matrix -> SparseNussinov::decode(p,ss,str) with threshold th. */
 int dafs_hip_consensus_structure(dafs_hip_ctx* ctx, uint32_t n, uint32_t len, const uint32_t* seq, const uint8_t* mask,
                                  float th, uint32_t* ss, float* score, float* p_out);
+
+/* DAFS::update_basepairing_probability (src/dafs.cpp:609-712; options --bp-update and --bp-update1), without the RNAalifold
+ * term: the sequences of the alignment (rows seq / mask as in dafs_node_input) are folded again with CONTRAfold under the
+ * constraint the common structure ss (ss[i] = j for the left partner, DAFS_HIP_NONE otherwise, as the decoders return it)
+ * puts on each of them, and the constrained posteriors are averaged; p_out receives the len x len matrix. */
+int dafs_hip_update_basepairing(dafs_hip_ctx* ctx, uint32_t n, uint32_t len, const uint32_t* seq, const uint8_t* mask,
+                                const uint32_t* ss, float* p_out);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,9 @@ typedef struct {
   float th_s;        /* -t   default 0.2  */
   float th_s1;       /* -T   default = th_s */
   int force_iters;   /* bench-only: ignore the violated==0 exit (never for parity) */
+  float w_pct_f;     /* -f   default 0.0: weight of the four-way consistency transform (dafs.cpp:377-444, :1808) */
+  int bp_update;     /* --bp-update  (dafs.cpp:1766): base-pairing matrices of the root node re-estimated under the decoded structure */
+  int bp_update1;    /* --bp-update1 (dafs.cpp:1767): the same for the final common structure */
 } orc_params;
 void orc_params_default(orc_params* p);
 

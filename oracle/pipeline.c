@@ -59,6 +59,7 @@ void orc_params_default(orc_params* p) { /* dafs.cpp:1612-1640 */
   p->w = 4.0f; p->eta0 = 0.5f; p->t_max = 600;
   p->w_pct_a = 0.25f; p->w_pct_s = 0.25f; p->th_a = 0.01f; p->th_s = 0.2f; p->th_s1 = 0.2f;
   p->force_iters = 0;
+  p->w_pct_f = 0.0f; p->bp_update = 0; p->bp_update1 = 0;
 }
 
 static void csr_alloc(orc_csr* m, uint32_t nrow, uint32_t cap) {
@@ -186,6 +187,58 @@ static void relax_matching_probability(orc_pipeline* pl) {
           }
       }
       dense_to_csr(&mp[(size_t)x * N + y], posterior, L1, L2, sum_w, 0);
+      orc_transpose(&mp[(size_t)x * N + y], L2, &mp[(size_t)y * N + x]);
+      free(posterior);
+    }
+  }
+  for (uint32_t x = 0; x != N; ++x) csr_identity(&mp[(size_t)x * N + x], pl->len[x]);
+  for (size_t e = 0; e < (size_t)N * N; ++e) orc_csr_free(&pl->mp[e]);
+  free(pl->mp);
+  pl->mp = mp;
+}
+
+/* DAFS::relax_fourway_consistency, dafs.cpp:377-444: mp_[x][y] is replaced by a mix of itself and the stacking
+ * evidence of the two base-pairing matrices (the loops, their order and the types of every product are the
+ * reference's: p_ik * (1.0 - w) is a double product added to a float cell, the other addends are float products). */
+static void relax_fourway_consistency(orc_pipeline* pl) {
+  const uint32_t N = pl->N;
+  const float w_pct_f = pl->prm.w_pct_f;
+  orc_csr* mp = (orc_csr*)calloc((size_t)N * N, sizeof(orc_csr));
+  for (uint32_t x = 0; x + 1 < N; ++x) {
+    const uint32_t L1 = pl->len[x];
+    const orc_csr* bx = &pl->bp[x];
+    for (uint32_t y = x + 1; y != N; ++y) {
+      const uint32_t L2 = pl->len[y];
+      const orc_csr* by = &pl->bp[y];
+      const orc_csr* m = MP(pl, x, y);
+      float* posterior = (float*)calloc((size_t)L1 * L2, sizeof(float));
+      for (uint32_t i = 0; i != L1; ++i) {
+        for (uint32_t a = m->rowptr[i]; a < m->rowptr[i + 1]; ++a) {
+          const uint32_t k = m->col[a];
+          const float p_ik = m->val[a];
+          posterior[(size_t)i * L2 + k] += p_ik * (1.0 - w_pct_f);
+          for (uint32_t b = bx->rowptr[i]; b < bx->rowptr[i + 1]; ++b) {
+            const uint32_t j = bx->col[b];
+            const float p_ij = bx->val[b];
+            uint32_t l1 = m->rowptr[j], e1 = m->rowptr[j + 1];
+            uint32_t l2 = by->rowptr[k], e2 = by->rowptr[k + 1];
+            while (l1 != e1 && l2 != e2) {
+              if (m->col[l1] < by->col[l2]) ++l1;
+              else if (m->col[l1] > by->col[l2]) ++l2;
+              else {
+                const uint32_t l = m->col[l1];
+                const float p_jl = m->val[l1];
+                const float p_kl = by->val[l2];
+                posterior[(size_t)i * L2 + k] += p_ij * p_kl * p_jl * w_pct_f;
+                posterior[(size_t)j * L2 + l] += p_ij * p_kl * p_ik * w_pct_f;
+                ++l1;
+                ++l2;
+              }
+            }
+          }
+        }
+      }
+      dense_to_csr(&mp[(size_t)x * N + y], posterior, L1, L2, 1.0f, 0); /* v > CUTOFF, :428-436 (x / 1.0f is x) */
       orc_transpose(&mp[(size_t)x * N + y], L2, &mp[(size_t)y * N + x]);
       free(posterior);
     }
@@ -385,6 +438,59 @@ static float* average_basepairing_probability(const orc_pipeline* pl, const aln_
       if (p[(size_t)i * L + j] <= CUTOFF) p[(size_t)i * L + j] = 0.0;
   free(idx);
   return p;
+}
+
+/* DAFS::update_basepairing_probability, dafs.cpp:609-712 (options --bp-update / --bp-update1), use_alifold == false and one
+ * level of brackets (th_s_.size() == 1): every sequence of the alignment is folded again under the constraint the
+ * decoded common structure ss / str puts on it (paired columns whose two residues exist: '(' and ')'; everything else
+ * '?'), and the constrained posteriors are averaged like the unconstrained ones. */
+static float* update_basepairing_probability(const orc_pipeline* pl, const aln_t* a, const uint32_t* ss, const char* str) {
+  const uint32_t L = a->L, N = a->n;
+  float* p = (float*)calloc((size_t)L * L, sizeof(float));
+  uint32_t* idx = (uint32_t*)malloc(((size_t)L + 1) * sizeof(uint32_t));
+  uint32_t* rev = (uint32_t*)malloc(((size_t)L + 1) * sizeof(uint32_t));
+  for (uint32_t r = 0; r < N; ++r) {
+    const uint32_t s = a->idx[r], Ls = pl->len[s];
+    const uint8_t* m = a->mask + (size_t)r * L;
+    for (uint32_t i = 0, j = 0; i != L; ++i) {
+      rev[i] = ORC_NONE;
+      if (m[i]) { idx[j] = i; rev[i] = j; j++; }
+    }
+    char* con = (char*)malloc((size_t)Ls + 1);
+    memset(con, '?', Ls);
+    con[Ls] = 0;
+    for (uint32_t i = 0; i != L; ++i)
+      if (ss[i] != ORC_NONE && rev[i] != ORC_NONE && rev[ss[i]] != ORC_NONE) {
+        if (str[i] == '(') { con[rev[i]] = '('; con[rev[ss[i]]] = ')'; } /* left_brackets[0], fold.cpp:57 */
+        else { con[rev[i]] = con[rev[ss[i]]] = '.'; }
+      }
+    orc_csr bp;
+    memset(&bp, 0, sizeof bp);
+    csr_alloc(&bp, Ls, (Ls * (Ls + 1)) / 2 + 1);
+    const int rc = orc_fold_calculate(pl->seqs[s], Ls, con, (float)CUTOFF, bp.rowptr, bp.col, bp.val); /* s_model_->calculate(seq, con, bp), :659 */
+    if (rc >= 0)
+      for (uint32_t i = 0; i != Ls; ++i)
+        for (uint32_t e = bp.rowptr[i]; e < bp.rowptr[i + 1]; ++e)
+          p[(size_t)idx[i] * L + idx[bp.col[e]]] += bp.val[e] / N;
+    orc_csr_free(&bp);
+    free(con);
+  }
+  for (uint32_t i = 0; i + 1 < L; ++i)
+    for (uint32_t j = i + 1; j != L; ++j)
+      if (p[(size_t)i * L + j] <= CUTOFF) p[(size_t)i * L + j] = 0.0;
+  free(idx); free(rev);
+  return p;
+}
+
+/* the `if (use_bp_update_)` blocks of DAFS::align_alignments(VU&, ...), dafs.cpp:919-934: decode, then re-estimate */
+static float* bp_update(const orc_pipeline* pl, const aln_t* a, float* p, float th) {
+  uint32_t* ss = (uint32_t*)malloc(((size_t)a->L + 1) * sizeof(uint32_t));
+  char* str = (char*)malloc((size_t)a->L + 1);
+  orc_nussinov_decode(th, 0.0f, a->L, p, NULL, ss);
+  orc_make_brackets(a->L, ss, str);
+  float* q = update_basepairing_probability(pl, a, ss, str);
+  free(ss); free(str); free(p);
+  return q;
 }
 
 typedef struct { uint32_t i, j, k, l; } cbp_t;
@@ -594,6 +700,10 @@ static void align_node(orc_pipeline* pl, aln_t* out, uint32_t ch) {
   align_node(pl, &a2, pl->tright[ch]);
   float* p_x = average_basepairing_probability(pl, &a1);
   float* p_y = average_basepairing_probability(pl, &a2);
+  if (pl->prm.bp_update && ch == 2 * pl->N - 2) { /* only the top call takes the overload with the update, dafs.cpp:1518-1537 */
+    p_x = bp_update(pl, &a1, p_x, pl->prm.th_s);
+    p_y = bp_update(pl, &a2, p_y, pl->prm.th_s);
+  }
   float* p_z = average_matching_probability(pl, &a1, &a2);
   uint32_t* x = (uint32_t*)malloc(((size_t)a1.L + 1) * sizeof(uint32_t));
   uint32_t* y = (uint32_t*)malloc(((size_t)a2.L + 1) * sizeof(uint32_t));
@@ -685,6 +795,7 @@ int orc_pipeline_phase1(orc_pipeline* pl) {
   }
   double t2 = now_s();
   pl->secs[1] = t2 - t1;
+  if (pl->prm.w_pct_f != 0.0) relax_fourway_consistency(pl); /* :1808-1809, before the similarity scores */
   /* sim_ :1813-1819 */
   for (uint32_t i = 0; i < N; ++i) {
     SIM(pl, i, i) = 1.0;
@@ -718,6 +829,7 @@ int orc_pipeline_phase2(orc_pipeline* pl) {
   aln_t* a = &pl->final_aln;
   /* final common structure :1857-1871 -- WITHOUT the alifold term (see header) */
   float* p = average_basepairing_probability(pl, a);
+  if (pl->prm.bp_update1) p = bp_update(pl, a, p, pl->prm.th_s1); /* :1863-1869 */
   free(pl->final_ss); free(pl->final_str);
   pl->final_ss = (uint32_t*)malloc(((size_t)a->L + 1) * sizeof(uint32_t));
   pl->final_str = (char*)malloc((size_t)a->L + 1);

@@ -19,7 +19,8 @@ def _build():
 class OrcParams(C.Structure):
     _fields_ = [("align_model", C.c_int), ("fold_model", C.c_int), ("w", C.c_float), ("eta0", C.c_float),
                 ("t_max", C.c_uint), ("w_pct_a", C.c_float), ("w_pct_s", C.c_float), ("th_a", C.c_float),
-                ("th_s", C.c_float), ("th_s1", C.c_float), ("force_iters", C.c_int)]
+                ("th_s", C.c_float), ("th_s1", C.c_float), ("force_iters", C.c_int), ("w_pct_f", C.c_float),
+                ("bp_update", C.c_int), ("bp_update1", C.c_int)]
 
 
 class OrcCsr(C.Structure):

@@ -60,6 +60,27 @@ def test_contralign_and_flags(oracle):
     assert out == oracle_output(oracle, path, th_s=np.float32(1.0 / 5.0), th_s1=np.float32(0.5))[0]
 
 
+def test_fourway_and_bp_update_flags(oracle, tmp_path):
+    """-f (relax_fourway_consistency, dafs.cpp:377-444), --bp-update (root node, :919-934) and --bp-update1 (final structure,
+    :1863-1869) through the command line and through the Python driver, against the oracle pipeline.  Parity unpinned:
+    the oracle restates dafs.cpp, which cannot be built in this image."""
+    from dafs_amd import pipeline
+    recs = synth.family_set(6, 70, seed=31)
+    fa = tmp_path / "fam.fa"
+    fa.write_text(synth.to_fasta(recs))
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    for args, kw, pkw in ((["-f", "0.4"], dict(w_pct_f=0.4), dict(w_pct_f=0.4)),
+                          (["--bp-update"], dict(bp_update=1), dict(bp_update=True)),
+                          (["--bp-update1"], dict(bp_update1=1), dict(bp_update1=True)),
+                          (["-f", "0.2", "--bp-update", "--bp-update1", "-m", "40"], dict(w_pct_f=0.2, bp_update=1, bp_update1=1, t_max=40),
+                           dict(w_pct_f=0.2, bp_update=True, bp_update1=True, t_max=40))):
+        want, _ = oracle_output(oracle, str(fa), **kw)
+        rc, out, err = run_cli(*(args + [str(fa)]))
+        assert rc == 0, err
+        assert out == want, args
+        assert pipeline.run(names, seqs, **pkw).output == want, args
+
+
 def test_synthetic_family_verbose_log(oracle, tmp_path):
     recs = synth.family_set(12, 90, seed=5)
     fa = tmp_path / "fam.fa"

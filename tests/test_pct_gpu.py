@@ -27,14 +27,16 @@ def random_bp(seqs, seed, density=0.03):
     return out
 
 
-def check_phase1(oracle, names, seqs, bp, w_a=0.25, w_s=0.25):
+def check_phase1(oracle, names, seqs, bp, w_a=0.25, w_s=0.25, w_f=0.0):
     from dafs_amd import capi
-    pl = oracle.pipeline(names, seqs, oracle.params(fold_model=1, w_pct_a=w_a, w_pct_s=w_s), bp=bp)
+    pl = oracle.pipeline(names, seqs, oracle.params(fold_model=1, w_pct_a=w_a, w_pct_s=w_s, w_pct_f=w_f), bp=bp)
     pl.phase1()
     ctx = capi.Context(0)
     ctx.set_sequences(seqs)
     ctx.set_bp(bp)
     ctx.align_posteriors(fetch=False)
+    if w_f != 0:
+        ctx.fourway_consistency(w_f)  # replaces the un-relaxed store and the similarity scores (dafs.cpp:1808)
     assert ctx.sim().tobytes() == pl.sim().tobytes()
     ctx.consistency(w_a, w_s)
     n = len(seqs)
@@ -80,3 +82,21 @@ def test_weights_off_and_negative(oracle):
     check_phase1(oracle, names, seqs, bp, w_a=0.0, w_s=0.25)
     check_phase1(oracle, names, seqs, bp, w_a=0.25, w_s=0.0)
     check_phase1(oracle, names, seqs, bp, w_a=-1.0, w_s=-1.0)
+
+
+@pytest.mark.parametrize("w_f", [0.3, 1.0])
+def test_fourway_consistency(oracle, w_f):
+    """DAFS::relax_fourway_consistency (-f, dafs.cpp:377-444): the transformed matching rows, the similarity scores taken
+    from them and both ordinary transforms on top, against the oracle pipeline (parity unpinned: the oracle restates
+    dafs.cpp, which cannot be built here); and the whole run through the driver."""
+    from dafs_amd import pipeline
+    recs = synth.family_set(7, 80, seed=17)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    bp = random_bp(seqs, 6, density=0.05)
+    check_phase1(oracle, names, seqs, bp, w_f=w_f)
+    check_phase1(oracle, names, seqs, bp, w_a=0.0, w_s=0.0, w_f=w_f)  # the transformed rows themselves
+    pl = oracle.pipeline(names, seqs, oracle.params(fold_model=1, w_pct_f=w_f), bp=bp)
+    pl.phase1(); pl.phase2()
+    got = pipeline.run(names, seqs, bp=bp, w_pct_f=w_f, skip_uncoupled_folds=False)
+    assert got.output == pl.output()
+    pl.close()
