@@ -721,47 +721,110 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
 #pragma unroll
   for (int c = 0; c < W; ++c) asm volatile("" : "+v"(Pc[c]), "+v"(Qc[c]));  // nothing pending at the loop header (see nuss_wave_reg)
   asm volatile("" : "+v"(ef), "+v"(es));
-  for (int s = 0; s < nsteps; ++s) {
-    const int i = s - lane + 1;
-    const bool rowv = i >= 1 && i <= (int)L1;
-    if (s + 1 < nsteps) {
+  if constexpr (TRL) {
+    // The form with the packed table in LDS, straight-line: every cell is computed and then replaced by what its place in
+    // the grid says (outside the envelope: lowest(); column 0: 0; rows and columns outside the grid: unchanged), and the
+    // codes of the lane's W cells -- consecutive cells of one row -- go out together, as one 64-bit value shifted to its
+    // place: two ds_or instead of one per cell with its own address arithmetic.
+    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+    const int k0 = lane * W;
+    const bool lane0 = lane == 0;
+    for (int s = 0; s < nsteps; ++s) {
+      const int i = s - lane + 1;
+      const bool rowv = i >= 1 && i <= (int)L1;
+      if (s + 1 < nsteps) {
 #pragma unroll
-      for (int c = 0; c < W; ++c) { np[c] = ps[((size_t)(s + 1) * W + c) * 64 + lane]; nq[c] = qs[((size_t)(s + 1) * W + c) * 64 + lane]; }
-    }
-    const bool nrow = i + 1 >= 1 && i + 1 <= (int)L1;
-    const uint32_t nef = nrow ? env[2 * (i + 1)] : 1u, nes = nrow ? env[2 * (i + 1) + 1] : 0u;
-    const float recv = wave_shr1(last);  // lane 0 owns column 0, which takes nothing from its left
-    float diag = leftprev;
-    float left = recv;
-    float v = 0.0f;
-#pragma unroll
-    for (int c = 0; c < W; ++c) {
-      const uint32_t k = lane * W + c;
-      const float up = P[c];
-      v = up;
-      if (rowv && k <= L2) {
-        if (k == 0) v = 0.0f;
-        else if (k >= ef && k <= es) {
-          v = diag + Pc[c] - th;
-          v = v + Qc[c];
-          uint32_t t = 1;
-          if (v < up) { v = up; t = 2; }
-          if (v < left) { v = left; t = 3; }
-          if (TRL) {
-            const uint32_t q = (uint32_t)i * T + k;
-            __hip_atomic_fetch_or(&tr_l[q >> 4], t << ((q & 15u) * 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          } else tr_g[(size_t)i * T + k] = t == 1 ? 'M' : (t == 2 ? 'X' : 'Y');
-        } else v = -FLT_MAX;
+        for (int c = 0; c < W; ++c) { np[c] = ps[((size_t)(s + 1) * W + c) * 64 + lane]; nq[c] = qs[((size_t)(s + 1) * W + c) * 64 + lane]; }
       }
-      diag = up;
-      P[c] = v;
-      left = v;
-    }
-    leftprev = recv;
-    last = v;
-    ef = nef; es = nes;
+      // envelope of the next row: one 8-byte load at a clamped row (rows outside 1..L1 get the empty range)
+      const int in = i + 1;
+      const bool nrow = in >= 1 && in <= (int)L1;
+      const v2u ne = *(DD_GLB const v2u*)(env + 2 * (uint32_t)(in < 0 ? 0 : (in > (int)L1 ? (int)L1 : in)));
+      const float recv = wave_shr1(last);  // lane 0 owns column 0, which takes nothing from its left
+      // this row's cells of the envelope are the columns lo..hi (none when the lane is outside the rows)
+      const int lo = rowv ? (int)(ef > 1u ? ef : 1u) : 1, hi = rowv ? (int)es : 0;
+      const int kmax = rowv ? (int)L2 : -1;  // columns of the grid in this row
+      float diag = leftprev;
+      float left = recv;
+      float v = 0.0f;
+      unsigned long long codes = 0;
 #pragma unroll
-    for (int c = 0; c < W; ++c) { Pc[c] = np[c]; Qc[c] = nq[c]; }
+      for (int c = 0; c < W; ++c) {
+        const int k = k0 + c;
+        const float up = P[c];
+        float cand = diag + Pc[c] - th;  // needleman_wunsch.cpp:281-283
+        cand = cand + Qc[c];
+        const bool m1 = cand < up;
+        const float v1 = m1 ? up : cand;
+        const bool m2 = v1 < left;
+        const float v2 = m2 ? left : v1;
+        const uint32_t t = m2 ? 3u : (m1 ? 2u : 1u);
+        const bool inside = k >= lo && k <= hi;
+        v = inside ? v2 : -FLT_MAX;
+        if (c == 0) v = lane0 ? 0.0f : v;  // column 0
+        v = k <= kmax ? v : up;            // outside the grid: the cell keeps what it held (row 0 / the last row)
+        codes |= (unsigned long long)(inside ? t : 0u) << (2 * c);
+        diag = up;
+        P[c] = v;
+        left = v;
+      }
+      if (codes) {  // cells (i, k0 .. k0+W-1): bit position 2 q, q = i*T + k0
+        const uint32_t q = (uint32_t)i * T + (uint32_t)k0;
+        const uint32_t sh = (q & 15u) * 2u;
+        const unsigned long long w = codes << sh;
+        DD_LDS uint32_t* word = tr_l + (q >> 4);
+        __hip_atomic_fetch_or(word, (uint32_t)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((uint32_t)(w >> 32)) __hip_atomic_fetch_or(word + 1, (uint32_t)(w >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      leftprev = recv;
+      last = v;
+      ef = nrow ? ne.x : 1u; es = nrow ? ne.y : 0u;
+#pragma unroll
+      for (int c = 0; c < W; ++c) { Pc[c] = np[c]; Qc[c] = nq[c]; }
+    }
+  } else {
+  for (int s = 0; s < nsteps; ++s) {
+      const int i = s - lane + 1;
+      const bool rowv = i >= 1 && i <= (int)L1;
+      if (s + 1 < nsteps) {
+  #pragma unroll
+        for (int c = 0; c < W; ++c) { np[c] = ps[((size_t)(s + 1) * W + c) * 64 + lane]; nq[c] = qs[((size_t)(s + 1) * W + c) * 64 + lane]; }
+      }
+      const bool nrow = i + 1 >= 1 && i + 1 <= (int)L1;
+      const uint32_t nef = nrow ? env[2 * (i + 1)] : 1u, nes = nrow ? env[2 * (i + 1) + 1] : 0u;
+      const float recv = wave_shr1(last);  // lane 0 owns column 0, which takes nothing from its left
+      float diag = leftprev;
+      float left = recv;
+      float v = 0.0f;
+  #pragma unroll
+      for (int c = 0; c < W; ++c) {
+        const uint32_t k = lane * W + c;
+        const float up = P[c];
+        v = up;
+        if (rowv && k <= L2) {
+          if (k == 0) v = 0.0f;
+          else if (k >= ef && k <= es) {
+            v = diag + Pc[c] - th;
+            v = v + Qc[c];
+            uint32_t t = 1;
+            if (v < up) { v = up; t = 2; }
+            if (v < left) { v = left; t = 3; }
+            if (TRL) {
+              const uint32_t q = (uint32_t)i * T + k;
+              __hip_atomic_fetch_or(&tr_l[q >> 4], t << ((q & 15u) * 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else tr_g[(size_t)i * T + k] = t == 1 ? 'M' : (t == 2 ? 'X' : 'Y');
+          } else v = -FLT_MAX;
+        }
+        diag = up;
+        P[c] = v;
+        left = v;
+      }
+      leftprev = recv;
+      last = v;
+      ef = nef; es = nes;
+  #pragma unroll
+      for (int c = 0; c < W; ++c) { Pc[c] = np[c]; Qc[c] = nq[c]; }
+    }
   }
   // dp[L1][L2]: what the lane that owns column L2 holds there after its last row (rows beyond L1 leave P untouched)
   float score = 0.0f;
