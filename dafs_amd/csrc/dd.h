@@ -82,6 +82,7 @@ int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, 
 int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, dd_params prm, hipStream_t st);
 #define DD_WREG 8     // widest lane (columns) of the register-resident alignment DP, and of the folding DP with its codes in LDS
 #define DD_WFOLD 16   // widest lane of the register-resident folding DP (codes in HBM beyond DD_WREG)
+#define DD_WNW 16     // widest lane of the register-resident alignment DP (second alignments up to 1023 columns)
 #define DD_CAP 4  // candidates per column kept in LDS by the fast folding DP
 // LDS words of the in-flight rows of a fast folding DP: one row of L values per active lane (the lanes own
 // ceil(L/64) columns each, so ceil(L / that) of them are at work).  The previous-row buffers and candidate counters of

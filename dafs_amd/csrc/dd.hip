@@ -257,7 +257,7 @@ __device__ __forceinline__ size_t tri_index(uint32_t L, uint32_t i, uint32_t j) 
 #define DD_WMAX 16  // columns per lane whose next-step inputs are prefetched through registers by nw_wave; wider lanes (alignments
                    // beyond 1024 columns, up to DD_LMAX) fetch the rest at the end of the step
 
-// Register-resident forms (W columns per lane, a template constant: up to DD_WREG for the alignment DP and for
+// Register-resident forms (W columns per lane, a template constant: up to DD_WNW for the alignment DP, DD_WREG for
 // the folding DP with its codes in LDS, up to DD_WFOLD for the folding DP with its codes in HBM): the previous
 // row, the scores and the candidates of the lane's columns live in registers; the only LDS traffic of a cell
 // is publishing its value and code and reading the dp[i][k-1] of its column's candidates (fetched a step
@@ -844,7 +844,15 @@ __device__ __noinline__ float nw_wave_fast(uint32_t W, uint32_t L1, uint32_t L2,
     case 5: return nw_wave_reg<5, TRL>(L1, L2, ps, qs, th, env, tr, lane);
     case 6: return nw_wave_reg<6, TRL>(L1, L2, ps, qs, th, env, tr, lane);
     case 7: return nw_wave_reg<7, TRL>(L1, L2, ps, qs, th, env, tr, lane);
-    default: return nw_wave_reg<8, TRL>(L1, L2, ps, qs, th, env, tr, lane);
+    case 8: return nw_wave_reg<8, TRL>(L1, L2, ps, qs, th, env, tr, lane);
+    case 9: return nw_wave_reg<9, TRL>(L1, L2, ps, qs, th, env, tr, lane);
+    case 10: return nw_wave_reg<10, TRL>(L1, L2, ps, qs, th, env, tr, lane);
+    case 11: return nw_wave_reg<11, TRL>(L1, L2, ps, qs, th, env, tr, lane);
+    case 12: return nw_wave_reg<12, TRL>(L1, L2, ps, qs, th, env, tr, lane);
+    case 13: return nw_wave_reg<13, TRL>(L1, L2, ps, qs, th, env, tr, lane);
+    case 14: return nw_wave_reg<14, TRL>(L1, L2, ps, qs, th, env, tr, lane);
+    case 15: return nw_wave_reg<15, TRL>(L1, L2, ps, qs, th, env, tr, lane);
+    default: return nw_wave_reg<16, TRL>(L1, L2, ps, qs, th, env, tr, lane);  // DD_WNW
   }
 }
 
@@ -1675,11 +1683,11 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     if (wave == 2) {
       float sc;
       const unsigned long long tz0 = prm.stamps ? wall_clock64() : 0ull;
-      if (Wz <= DD_WREG && !nw_lean) sc = trzp ? nw_wave_fast<true>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, (uint8_t*)trzp, lane)
+      if (Wz <= DD_WNW && !nw_lean) sc = trzp ? nw_wave_fast<true>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, (uint8_t*)trzp, lane)
                                    : nw_wave_fast<false>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, trz, lane);
       else sc = nw_wave(L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, trz, Pz, Pbz, Qbz, lane);
       bool ok = true;
-      if (trzp && Wz <= DD_WREG && !nw_lean) { wave_lds_fence(); ok = nw_traceback_wave(L1, L2, trzp, nd.z, lane); }  // by the whole wavefront
+      if (trzp && Wz <= DD_WNW && !nw_lean) { wave_lds_fence(); ok = nw_traceback_wave(L1, L2, trzp, nd.z, lane); }  // by the whole wavefront
       else if (lane == 0) ok = nw_traceback(L1, L2, trz, nd.z);
       if (lane == 0) {
         s_score[2] = sc;
