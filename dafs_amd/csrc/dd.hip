@@ -1413,7 +1413,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_cbp_fill(const dd_node* nod
 __device__ __forceinline__ uint32_t sync_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sync_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __noinline__ void dd_folder(const dd_node& nd, const dd_params& prm, uint32_t role, uint32_t t_first) {
+__device__ __forceinline__ void dd_folder(const dd_node& nd, const dd_params& prm, uint32_t role, uint32_t t_first) {
   extern __shared__ unsigned char s_dd[];
   __shared__ float s_fscore;
   __shared__ uint32_t s_go, s_slow;
