@@ -416,14 +416,14 @@ int nodes_open(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const dafs_n
   }
   if ((rc = ln.d_nodes->upload(nodes.data(), nnodes, ln.st))) return rc;
   if ((rc = dd_cbp_fill_launch(ln.d_nodes->ptr, nnodes, force_wide ? 0 : max_len, dp, ln.st))) return rc;
-  for (uint32_t b = 0; b < nnodes; ++b) c->dd_open.push_back({nodes[b], lds[b], split_lds[b], false, {blk0[b], blk1[b]}, {blk0_bytes[b], blk1_bytes[b]}, false, false});
+  for (uint32_t b = 0; b < nnodes; ++b) c->dd_open.push_back({nodes[b], lds[b], split_lds[b], false, {blk0[b], blk1[b]}, {blk0_bytes[b], blk1_bytes[b]}, false, false, {}});
   return DAFS_HIP_OK;
 }
 
 // One launch of the subgradient loop over the given resident nodes; finished[k] tells which of them are done.
 // In two halves, so that launches on two lanes can be in flight together: advance_launch enqueues the kernel and the
 // copy of the per-node words, advance_collect waits for them.
-struct advance_state { std::vector<uint32_t> who, handles; const uint32_t* paused = nullptr; bool launched = false; };
+struct advance_state { std::vector<uint32_t> who, handles, off; const uint32_t* paused = nullptr; const uint32_t* packed = nullptr; bool launched = false; };
 
 int advance_launch(dafs_hip_ctx* c, const dd_lane& ln, uint32_t n, const uint32_t* handles, dd_params dp, uint32_t max_iterations, uint8_t* finished,
                    advance_state& stt) {
@@ -467,10 +467,24 @@ int advance_launch(dafs_hip_ctx* c, const dd_lane& ln, uint32_t n, const uint32_
   if ((rc = ln.d_nodes->upload(nodes.data(), nodes.size(), ln.st))) return rc;
   if ((rc = ln.d_paused->reserve(nodes.size()))) return rc;
   if ((rc = dd_solve_launch(ln.d_nodes->ptr, (uint32_t)nodes.size(), dp, lds_max, split, ln.d_paused->ptr, ln.st))) return rc;
-  uint32_t* landing = c->pinned_words(ln.id, nodes.size());
+  // the result words of every node of the launch come along (one packed copy): a node that finishes here needs no
+  // copy and no synchronisation of its own in dafs_hip_nodes_result
+  stt.off.assign(nodes.size() + 1, 0);
+  for (size_t b = 0; b < nodes.size(); ++b) stt.off[b + 1] = stt.off[b] + (uint32_t)((nodes[b].info + 16) - nodes[b].x);
+  const size_t total = stt.off[nodes.size()];
+  dev_buf<uint32_t>& d_off = c->d_pack_off[ln.id];
+  dev_buf<uint32_t>& d_pack = c->d_pack[ln.id];
+  if ((rc = d_off.reserve(nodes.size()))) return rc;
+  if ((rc = d_pack.reserve(total))) return rc;
+  uint32_t* landing = c->pinned_words(ln.id, 2 * nodes.size() + total);
   if (!landing) return DAFS_HIP_ENOMEM;
+  memcpy(landing + nodes.size(), stt.off.data(), nodes.size() * 4);  // staged in pinned memory: the upload stays asynchronous
+  if (hip_check(hipMemcpyAsync(d_off.ptr, landing + nodes.size(), nodes.size() * 4, hipMemcpyHostToDevice, ln.st))) return DAFS_HIP_ELAUNCH;
+  if ((rc = dd_pack_launch(ln.d_nodes->ptr, (uint32_t)nodes.size(), d_off.ptr, d_pack.ptr, ln.st))) return rc;
   stt.paused = landing;
+  stt.packed = landing + 2 * nodes.size();
   if (hip_check(hipMemcpyAsync(landing, ln.d_paused->ptr, nodes.size() * 4, hipMemcpyDeviceToHost, ln.st))) return DAFS_HIP_ELAUNCH;
+  if (total && hip_check(hipMemcpyAsync(landing + 2 * nodes.size(), d_pack.ptr, total * 4, hipMemcpyDeviceToHost, ln.st))) return DAFS_HIP_ELAUNCH;
   stt.launched = true;
   return DAFS_HIP_OK;
 }
@@ -483,6 +497,7 @@ int advance_collect(dafs_hip_ctx* c, const dd_lane& ln, advance_state& stt, uint
     const bool done = stt.paused[b] == 0;
     if (stt.paused[b] == 2) c->dd_open[h].no_split = true;  // its folders were lost: from now on the one-workgroup form
     c->dd_open[h].finished = done;
+    if (done) c->dd_open[h].result.assign(stt.packed + stt.off[b], stt.packed + stt.off[b + 1]);
     if (finished) finished[stt.who[b]] = done ? 1 : 0;
   }
   stt.launched = false;
@@ -506,7 +521,9 @@ int nodes_result(dafs_hip_ctx* c, uint32_t handle, dafs_node_output* out, bool s
   const uint8_t* hi = (const uint8_t*)(nd.info + 16);
   if (hi <= lo || (size_t)(hi - lo) > ((size_t)2 * nd.L1 + nd.L2 + 64) * 4 + 8 * 256) return DAFS_HIP_EINVAL;
   std::vector<uint8_t> blob((size_t)(hi - lo));
-  if (hip_check(hipMemcpyAsync(blob.data(), lo, blob.size(), hipMemcpyDeviceToHost, c->stream)) || hip_check(hipStreamSynchronize(c->stream)))
+  const std::vector<uint32_t>& pre = c->dd_open[handle].result;
+  if (pre.size() * 4 == blob.size()) memcpy(blob.data(), pre.data(), blob.size());  // came along with the launch the node finished in
+  else if (hip_check(hipMemcpyAsync(blob.data(), lo, blob.size(), hipMemcpyDeviceToHost, c->stream)) || hip_check(hipStreamSynchronize(c->stream)))
     return DAFS_HIP_ELAUNCH;
   auto at = [&](const void* dev_ptr) { return blob.data() + ((const uint8_t*)dev_ptr - lo); };
   if (out->x) memcpy(out->x, at(nd.x), (size_t)nd.L1 * 4);

@@ -129,6 +129,7 @@ struct dafs_hip_ctx {
   dafs::dev_buf<uint32_t> d_paused;  // per node of a launch: still unfinished
   dafs::dev_buf<dafs::dd_node> d_nodes2;  // the same pair for the second lane of dafs_hip_nodes_round
   dafs::dev_buf<uint32_t> d_paused2;
+  dafs::dev_buf<uint32_t> d_pack_off[2], d_pack[2];  // per lane: where each node's result words go in the packed buffer, and that buffer
   dafs::dev_buf<unsigned long long> d_tref;  // start tick of a round's first launch: the lanes of a round share one deadline
   // pinned landing places of the per-node words of a launch, one per lane: a copy into pageable memory would make the
   // "asynchronous" copy wait for the kernel in front of it, and the second lane could not start beside the first
@@ -152,7 +153,7 @@ struct dafs_hip_ctx {
   std::map<uint8_t*, size_t> dd_free_blocks;  // start -> bytes
   size_t dd_in_use = 0, dd_peak = 0;
   struct dd_open_node { dafs::dd_node nd; size_t lds, split_lds; bool finished; uint8_t* blk[2]; size_t blk_bytes[2]; bool released;
-                        bool no_split; };  // no_split: a launch lost this node's folding workgroups once (k_dd_solve), keep it on one workgroup
+                        bool no_split; std::vector<uint32_t> result; };  // result: the node's result words, brought along by the launch it finished in  // no_split: a launch lost this node's folding workgroups once (k_dd_solve), keep it on one workgroup
   std::vector<dd_open_node> dd_open;
   void dd_free(uint8_t* p, size_t bytes) {
     if (!p || !bytes) return;
@@ -214,7 +215,7 @@ struct dafs_hip_ctx {
 
   void free_all() {
     codes.release(); d_len.release(); d_seq_rp_off.release(); tasks.release(); scratch.release(); task_sim.release();
-    counters.release(); d_sim.release(); d_pair_x.release(); d_pair_y.release(); work.release(); work2.release(); d_nodes.release(); d_paused.release(); d_nodes2.release(); d_paused2.release(); d_tref.release(); dd_release();
+    counters.release(); d_sim.release(); d_pair_x.release(); d_pair_y.release(); work.release(); work2.release(); d_nodes.release(); d_paused.release(); d_nodes2.release(); d_paused2.release(); d_tref.release(); for (int k = 0; k < 2; ++k) { d_pack_off[k].release(); d_pack[k].release(); } dd_release();
     for (int k = 0; k < 2; ++k) { if (h_paused[k]) (void)hipHostFree(h_paused[k]); h_paused[k] = nullptr; h_paused_cap[k] = 0; }
     d_cf_params.release(); cf_seqs.release(); cf_codes.release(); cf_iws.release(); cf_cons.release(); cf_fws.release(); cf_post.release(); cf_logz.release();
     for (int k = 0; k < 2; ++k) { mp[k].release(); bp[k].release(); }

@@ -104,6 +104,7 @@ static inline __host__ __device__ uint32_t dd_span_nib_words(uint32_t L) { retur
 static inline __host__ __device__ uint32_t dd_span_tri_words(uint32_t L) { return (uint32_t)(((size_t)L * (L + 1) / 2 + 3) & ~(size_t)3); }
 static inline __host__ __device__ uint32_t dd_span_words(uint32_t L) { return dd_span_nib_words(L) + dd_span_tri_words(L) + 2 * DD_CAP * (L + 1) + DD_CAP * L; }
 static const size_t kDdLdsBudget = 156 * 1024;  // dynamic LDS of k_dd_solve (the CU has 160 KB; ~2.2 KB is static)
+int dd_pack_launch(const dd_node* d_nodes, uint32_t nnodes, const uint32_t* d_off, uint32_t* d_out, hipStream_t st);
 int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, bool split, uint32_t* d_paused, hipStream_t st);
 // standalone decoders on dense device matrices (one workgroup each)
 int nussinov_launch(uint32_t L, const float* p, const float* q, float w, float th, nuss_ws ws, uint32_t* ss, float* score, hipStream_t st);

@@ -1984,6 +1984,21 @@ int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len
   hipLaunchKernelGGL(k_node_cbp_fill, dim3(nnodes), dim3(DD_THREADS), lds, st, d_nodes, prm, (uint32_t)lds);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
+// The result words of every node of a launch (x, y, z, score, info: carved back to back in the node's block) gathered
+// into one buffer, so that one copy brings the results of all the nodes that finished in the launch.
+__global__ __launch_bounds__(256) void k_node_pack(const dd_node* nodes, const uint32_t* off_words, uint32_t* out) {
+  const dd_node& nd = nodes[blockIdx.x];
+  const uint32_t* src = nd.x;
+  const uint32_t n = (uint32_t)((nd.info + 16) - nd.x);
+  uint32_t* dst = out + off_words[blockIdx.x];
+  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) dst[k] = src[k];
+}
+int dd_pack_launch(const dd_node* d_nodes, uint32_t nnodes, const uint32_t* d_off, uint32_t* d_out, hipStream_t st) {
+  if (!nnodes) return DAFS_HIP_OK;
+  hipLaunchKernelGGL(k_node_pack, dim3(nnodes), dim3(256), 0, st, d_nodes, d_off, d_out);
+  return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
+}
+
 int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, bool split, uint32_t* d_paused, hipStream_t st) {
   if (!nnodes) return DAFS_HIP_OK;
   if (lds_bytes > kDdLdsBudget) return DAFS_HIP_EINVAL;
