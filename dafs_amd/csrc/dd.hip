@@ -1515,7 +1515,6 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
   const uint32_t npx = nd.px_ptr[L1], npy = nd.py_ptr[L2], ncz = nd.cz_ptr[L1];
   const float w_x = prm.w * 2 * nd.n1 / (nd.n1 + nd.n2);  // dafs.cpp:1091
   const float w_y = prm.w * 2 * nd.n2 / (nd.n1 + nd.n2);  // :1092
-  __shared__ uint32_t s_cnt[DD_THREADS];
   __shared__ uint32_t s_violated, s_npos;
   __shared__ int s_stop, s_bad, s_lost;  // s_lost: a folder of this split node did not answer in time
   __shared__ float s_eta;
@@ -1697,9 +1696,45 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     }
     DD_TICK(0);
     if (tid >= 192) {
-      for (uint32_t e = tid - 192; e < npx; e += nt - 192) nd.tx[e] = 0;
-      for (uint32_t e = tid - 192; e < npy; e += nt - 192) nd.ty[e] = 0;
-      for (uint32_t e = tid - 192; e < ncz; e += nt - 192) nd.tz[e] = 0;
+      // The fourth wavefront, beside the three DPs: the consensus constraints (:1103-1117).  s_w of a consensus pair is a
+      // sum of multipliers as the previous iteration left them -- nothing of this iteration's subproblems enters -- so
+      // the counts (atomics) and the list of positive s_w (compacted in consensus-pair order: the dual value adds them in
+      // that order) are ready when the DPs are.
+      const uint32_t l3 = tid - 192;
+      for (uint32_t e = l3; e < npx; e += 64) nd.tx[e] = 0;
+      for (uint32_t e = l3; e < npy; e += 64) nd.ty[e] = 0;
+      for (uint32_t e = l3; e < ncz; e += 64) nd.tz[e] = 0;
+      __threadfence();  // the zeros are in place before the first count
+      const uint32_t chunk = (ncbp + 63) / 64;
+      const uint32_t u0 = l3 * chunk < ncbp ? l3 * chunk : ncbp;
+      const uint32_t u1 = u0 + chunk < ncbp ? u0 + chunk : ncbp;
+      uint32_t npos = 0;
+      for (uint32_t u = u0; u < u1; ++u) {
+        const uint32_t* cb = nd.cbp + (size_t)8 * u;
+        const float s_w = nd.q_x[(size_t)cb[0] * L1 + cb[1]] + nd.q_y[(size_t)cb[2] * L2 + cb[3]] -
+                          nd.q_z[(size_t)cb[0] * L2 + cb[2]] - nd.q_z[(size_t)cb[1] * L2 + cb[3]];
+        if (s_w > 0.0f) {
+          ++npos;
+          atomicAdd(&nd.tx[cb[4]], 1);
+          atomicAdd(&nd.ty[cb[5]], 1);
+          atomicAdd(&nd.tz[cb[6]], 1);
+          atomicAdd(&nd.tz[cb[7]], 1);
+        }
+      }
+      uint32_t incl = npos;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if ((int)l3 >= o) incl += up;
+      }
+      if (l3 == 63) s_npos = incl;
+      uint32_t pos = incl - npos;
+      for (uint32_t u = u0; u < u1; ++u) {
+        const uint32_t* cb = nd.cbp + (size_t)8 * u;
+        const float s_w = nd.q_x[(size_t)cb[0] * L1 + cb[1]] + nd.q_y[(size_t)cb[2] * L2 + cb[3]] -
+                          nd.q_z[(size_t)cb[0] * L2 + cb[2]] - nd.q_z[(size_t)cb[1] * L2 + cb[3]];
+        if (s_w > 0.0f) nd.sw[pos++] = s_w;
+      }
     }
     if (tid == 0) {
       s_violated = 0;
@@ -1738,50 +1773,6 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     }
     DD_TICK(2);
 
-    // consensus constraints (:1103-1117): counts by atomics, positive s_w compacted in order
-    const uint32_t chunk = (ncbp + nt - 1) / nt;
-    const uint32_t u0 = tid * chunk < ncbp ? tid * chunk : ncbp;
-    const uint32_t u1 = u0 + chunk < ncbp ? u0 + chunk : ncbp;
-    uint32_t npos = 0;
-    float sw_first = 0.0f;  // the value of this thread's first consensus pair (its only one when chunk == 1)
-    for (uint32_t u = u0; u < u1; ++u) {
-      const uint32_t* cb = nd.cbp + (size_t)8 * u;
-      const float s_w = nd.q_x[(size_t)cb[0] * L1 + cb[1]] + nd.q_y[(size_t)cb[2] * L2 + cb[3]] -
-                        nd.q_z[(size_t)cb[0] * L2 + cb[2]] - nd.q_z[(size_t)cb[1] * L2 + cb[3]];
-      if (u == u0) sw_first = s_w;
-      if (s_w > 0.0f) {
-        ++npos;
-        atomicAdd(&nd.tx[cb[4]], 1);
-        atomicAdd(&nd.ty[cb[5]], 1);
-        atomicAdd(&nd.tz[cb[6]], 1);
-        atomicAdd(&nd.tz[cb[7]], 1);
-      }
-    }
-    // exclusive prefix of npos over the threads: a scan inside every wavefront, then the wavefront totals
-    uint32_t incl = npos;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = __shfl_up(incl, o);
-      if ((int)(tid & 63) >= o) incl += up;
-    }
-    if ((tid & 63) == 63) s_cnt[tid >> 6] = incl;
-    __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t wv = 0; wv < (tid >> 6); ++wv) before += s_cnt[wv];
-    if (tid == nt - 1) s_npos = before + incl;
-    {
-      uint32_t pos = before + incl - npos;
-      if (chunk == 1) {
-        if (npos) nd.sw[pos] = sw_first;
-      } else
-      for (uint32_t u = u0; u < u1; ++u) {
-        const uint32_t* cb = nd.cbp + (size_t)8 * u;
-        const float s_w = nd.q_x[(size_t)cb[0] * L1 + cb[1]] + nd.q_y[(size_t)cb[2] * L2 + cb[3]] -
-                          nd.q_z[(size_t)cb[0] * L2 + cb[2]] - nd.q_z[(size_t)cb[1] * L2 + cb[3]];
-        if (s_w > 0.0f) nd.sw[pos++] = s_w;
-      }
-    }
-    __syncthreads();
     DD_TICK(3);
     eta = s_eta;
 
