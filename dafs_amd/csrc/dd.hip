@@ -679,22 +679,31 @@ __device__ bool nw_traceback_wave(uint32_t L1, uint32_t L2, const uint32_t* tr_,
   };
   int i = (int)L1, k = (int)L2;
   uint32_t guard = L1 + L2 + 2;
+  // the code of the current cell; after a run it is what the lane that found the run's end has just read
+  uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)code(i, k));
   while ((i > 0 || k > 0) && guard--) {
-    const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)code(i, k));
+    uint32_t probe;
+    unsigned long long m;
     if (t == 1u) {         // (i,k), (i-1,k-1), ...: the run ends at the first cell whose code is not M
-      const unsigned long long m = __ballot(code(i - 1 - lane, k - 1 - lane) != 1u);
+      probe = code(i - 1 - lane, k - 1 - lane);
+      m = __ballot(probe != 1u);
       const int r = m ? (int)__ffsll((long long)m) - 1 : 63;  // cells of the run after the first (at most 64 cells a turn)
       if (lane <= r) al[i - 1 - lane] = (uint32_t)(k - 1 - lane);
       i -= 1 + r; k -= 1 + r;
+      t = m ? (uint32_t)__shfl((int)probe, r) : (uint32_t)__builtin_amdgcn_readfirstlane((int)code(i, k));
     } else if (t == 2u) {  // X run: rows i, i-1, ... of column k
-      const unsigned long long m = __ballot(code(i - 1 - lane, k) != 2u);
+      probe = code(i - 1 - lane, k);
+      m = __ballot(probe != 2u);
       const int r = m ? (int)__ffsll((long long)m) - 1 : 63;
       if (lane <= r) al[i - 1 - lane] = DD_NONE;
       i -= 1 + r;
+      t = m ? (uint32_t)__shfl((int)probe, r) : (uint32_t)__builtin_amdgcn_readfirstlane((int)code(i, k));
     } else if (t == 3u) {  // Y run
-      const unsigned long long m = __ballot(code(i, k - 1 - lane) != 3u);
+      probe = code(i, k - 1 - lane);
+      m = __ballot(probe != 3u);
       const int r = m ? (int)__ffsll((long long)m) - 1 : 63;
       k -= 1 + r;
+      t = m ? (uint32_t)__shfl((int)probe, r) : (uint32_t)__builtin_amdgcn_readfirstlane((int)code(i, k));
     } else return false;
   }
   return i == 0 && k == 0;
@@ -732,14 +741,19 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
     for (int s = 0; s < nsteps; ++s) {
       const int i = s - lane + 1;
       const bool rowv = i >= 1 && i <= (int)L1;
+      // envelope of the next row: one 8-byte load at a clamped row (rows outside 1..L1 get the empty range).  Issued
+      // BEFORE the prefetch of the next step's inputs: loads return in order, so the wait for it at the end of the step
+      // (vmcnt = the loads issued after it) leaves the prefetch in flight; the other way round every step would wait
+      // for its own prefetch.
+      const int in = i + 1;
+      const bool nrow = in >= 1 && in <= (int)L1;
+      const v2u ne = *(DD_GLB const v2u*)(env + 2 * (uint32_t)(in < 0 ? 0 : (in > (int)L1 ? (int)L1 : in)));
+      __builtin_amdgcn_sched_barrier(0);
       if (s + 1 < nsteps) {
 #pragma unroll
         for (int c = 0; c < W; ++c) { np[c] = ps[((size_t)(s + 1) * W + c) * 64 + lane]; nq[c] = qs[((size_t)(s + 1) * W + c) * 64 + lane]; }
       }
-      // envelope of the next row: one 8-byte load at a clamped row (rows outside 1..L1 get the empty range)
-      const int in = i + 1;
-      const bool nrow = in >= 1 && in <= (int)L1;
-      const v2u ne = *(DD_GLB const v2u*)(env + 2 * (uint32_t)(in < 0 ? 0 : (in > (int)L1 ? (int)L1 : in)));
+      __builtin_amdgcn_sched_barrier(0);
       const float recv = wave_shr1(last);  // lane 0 owns column 0, which takes nothing from its left
       // this row's cells of the envelope are the columns lo..hi (none when the lane is outside the rows)
       const int lo = rowv ? (int)(ef > 1u ? ef : 1u) : 1, hi = rowv ? (int)es : 0;
