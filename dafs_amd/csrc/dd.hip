@@ -1604,10 +1604,12 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
   if (!resume) {
     nw_init_tr(L1, L2, trz);
     // sweep-order inputs of the three DPs, built once; the multiplier updates below keep them current
-    if (nd.s_x) dd_fill_scores(false, L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_x);  // only foldings with a register form keep one
-    if (nd.s_y) dd_fill_scores(false, L2, nd.p_y, nd.q_y, w_y, prm.th_s, nd.s_y);
-    if (nd.s_xs) dd_fill_scores(true, L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_xs);  // the copy the span form reads
-    if (nd.s_ys) dd_fill_scores(true, L2, nd.p_y, nd.q_y, w_y, prm.th_s, nd.s_ys);
+    if (!(prm.skip_xy && ncbp == 0)) {  // a node that leaves its foldings out (see fold_on below) needs no scores
+      if (nd.s_x) dd_fill_scores(false, L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_x);  // only foldings with a register form keep one
+      if (nd.s_y) dd_fill_scores(false, L2, nd.p_y, nd.q_y, w_y, prm.th_s, nd.s_y);
+      if (nd.s_xs) dd_fill_scores(true, L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_xs);  // the copy the span form reads
+      if (nd.s_ys) dd_fill_scores(true, L2, nd.p_y, nd.q_y, w_y, prm.th_s, nd.s_ys);
+    }
     dd_fill_nw(L1, L2, nd.p_z, nd.q_z, nd.pz_s, nd.qz_s);
   }
   __syncthreads();
