@@ -387,7 +387,11 @@ int nodes_open(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const dafs_n
   const bp_store_dev bpv = bps.view();
   uint32_t max_len = 0;
   for (uint32_t b = 0; b < nnodes; ++b) max_len = std::max(max_len, std::max(in[b].len1, in[b].len2));
-  if ((rc = dd_avg_launch(ln.d_nodes->ptr, nnodes, max_len, mpv, bpv, force_wide ? 1 : 0, ln.st))) return rc;
+  // few nodes with hundreds of source rows per row of p_z (the top of the guide tree): a workgroup per p_z row
+  uint64_t srcs = 0;
+  for (uint32_t b = 0; b < nnodes; ++b) srcs = std::max<uint64_t>(srcs, (uint64_t)in[b].n1 * in[b].n2);
+  const int coop = (nnodes <= 4 && srcs >= 512 && !getenv("DAFS_HIP_AVG_COOP0")) ? 1 : 0;
+  if ((rc = dd_avg_launch(ln.d_nodes->ptr, nnodes, max_len, mpv, bpv, force_wide ? 1 : 0, coop, ln.st))) return rc;
   for (uint32_t b = 0; b < nnodes; ++b) {  // base-pairing matrices supplied by the caller (--bp-update) replace the averages
     const size_t XX = (size_t)in[b].len1 * in[b].len1, YY = (size_t)in[b].len2 * in[b].len2;
     if (in[b].p_x && hip_check(hipMemcpyAsync(nodes[b].p_x, in[b].p_x, XX * 4, hipMemcpyHostToDevice, ln.st))) return DAFS_HIP_ELAUNCH;
@@ -705,7 +709,7 @@ static int average_and_decode(dafs_hip_ctx* c, uint32_t n, uint32_t len, const u
   if ((rc = c->d_nodes.upload(&nd, 1, c->stream))) return rc;
   mp_store_dev none;
   memset(&none, 0, sizeof none);
-  if ((rc = dd_avg_launch(c->d_nodes.ptr, 1, len, none, bps.view(), 0, c->stream))) return rc;
+  if ((rc = dd_avg_launch(c->d_nodes.ptr, 1, len, none, bps.view(), 0, 0, c->stream))) return rc;
   float s = 0;
   if (decode) {
     if ((rc = nussinov_launch(len, nd.p_x, nullptr, 0.0f, th, nd.wx, d_ss, nd.score, c->stream))) return rc;

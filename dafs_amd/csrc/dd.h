@@ -77,7 +77,7 @@ struct dd_params {
   int t_ref_write;
 };
 
-int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_store_dev mp, bp_store_dev bp, int one_row, hipStream_t st);
+int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_store_dev mp, bp_store_dev bp, int one_row, int coop, hipStream_t st);
 int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, dd_params prm, uint32_t* d_ncbp, hipStream_t st);  // d_ncbp[b]: consensus pairs of node b
 int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, dd_params prm, hipStream_t st);
 #define DD_WREG 8     // widest lane (columns) of the register-resident alignment DP, and of the folding DP with its codes in LDS

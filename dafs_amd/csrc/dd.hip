@@ -1125,12 +1125,83 @@ __device__ void avg_row(uint32_t nsrc, float scale_div, GetSrc get, float* row, 
   }
 }
 
-__global__ __launch_bounds__(256) void k_node_avg(const dd_node* nodes, mp_store_dev mp, bp_store_dev bp, uint32_t row_cap) {
+// coop != 0 (launches of few nodes whose p_z rows have hundreds of source rows each: the top of the guide tree): a
+// workgroup per row of p_z.  A source is a chain of dependent loads (pair -> row pointers -> entries -> column map), and
+// a wavefront on its own walks the n1*n2 sources of its row 64 at a time; here the four wavefronts fetch four batches
+// at once, each into its own staging area, and the staged addends are then applied in batch order -- the order of the
+// sources, r1 major -- by all threads (a thread owns the columns congruent to it).
+__global__ __launch_bounds__(256) void k_node_avg(const dd_node* nodes, mp_store_dev mp, bp_store_dev bp, uint32_t row_cap, uint32_t coop) {
   extern __shared__ float s_rows[];  // (blockDim.x / 64) x row_cap: one accumulator row per wavefront
   __shared__ uint2 s_stage[4][AVG_STAGE];
+  __shared__ uint32_t s_total[4];
+  __shared__ uint32_t s_over;
   const dd_node nd = nodes[blockIdx.y];
   const uint32_t role = blockIdx.z;
   const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+  if (coop && role == 2) {
+    const uint32_t L1 = nd.L1, L2 = nd.L2, I = blockIdx.x, tid = threadIdx.x;
+    if (I >= L1) return;
+    const uint32_t nsrc = nd.n1 * nd.n2;
+    const float nn = (float)nsrc;
+    float* row = s_rows;
+    for (uint32_t J = tid; J < L2; J += 256) row[J] = 0.0f;
+    auto get = [&](uint32_t me) {
+      avg_src sr = {nullptr, nullptr, 0, nullptr};
+      const uint32_t r1 = me / nd.n2, r2 = me - r1 * nd.n2;
+      const uint32_t ii = nd.rank1[(size_t)r1 * L1 + I];
+      if (ii != DD_NONE) {
+        const row_ref m = mp_row(mp, nd.seq1[r1], nd.seq2[r2], ii);
+        sr.col = m.col; sr.val = m.val; sr.n = m.n; sr.map = nd.idx2 + nd.idxoff2[r2];
+      }
+      return sr;
+    };
+    __syncthreads();
+    for (uint32_t base = 0; base < nsrc; base += 256) {
+      if (tid == 0) s_over = 0;
+      __syncthreads();
+      {  // this wavefront's batch: sources base + 64 wave .. + 63, staged in source order
+        const uint32_t me = base + 64u * (uint32_t)wave + (uint32_t)lane;
+        avg_src sr = {nullptr, nullptr, 0, nullptr};
+        if (me < nsrc) sr = get(me);
+        uint32_t incl = sr.n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t up = __shfl_up(incl, o);
+          if (lane >= o) incl += up;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        if (total <= AVG_STAGE) {
+          const uint32_t pos = incl - sr.n;
+          for (uint32_t e = 0; e < sr.n; ++e) s_stage[wave][pos + e] = make_uint2(sr.map[sr.col[e]], __float_as_uint(sr.val[e] / nn));
+        } else if (lane == 0) s_over = 1;  // a batch that does not fit its staging area: the round goes the one-wavefront way
+        if (lane == 0) s_total[wave] = total;
+      }
+      __syncthreads();
+      if (s_over) {
+        if (wave == 0) {
+          const uint32_t hi = base + 256 < nsrc ? base + 256 : nsrc;
+          avg_row(hi - base, nn, [&](uint32_t k) { return get(base + k); }, row, s_stage[0], lane);
+        }
+      } else {
+        for (int w = 0; w < 4; ++w) {
+          const uint32_t total = s_total[w];
+          for (uint32_t k = 0; k < total; ++k) {
+            const uint2 a = s_stage[w][k];
+            if ((a.x & 255u) == tid) row[a.x] += __uint_as_float(a.y);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    float* P = nd.p_z + (size_t)I * L2;
+    for (uint32_t J = tid; J < L2; J += 256) {
+      float v = row[J];
+      if (v <= DD_CUTOFF) v = 0.0f;
+      if (v > 1.0f) v = 1.0f;
+      P[J] = v;
+    }
+    return;
+  }
   const uint32_t I = blockIdx.x * (blockDim.x >> 6) + wave;
   float* row = s_rows + (size_t)wave * row_cap;
   uint2* stage = s_stage[wave];
@@ -1957,7 +2028,7 @@ static int lds_optin(const void* fn, int slot, size_t bytes, size_t budget = kDd
   return DAFS_HIP_OK;
 }
 
-int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_store_dev mp, bp_store_dev bp, int one_row, hipStream_t st) {
+int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_store_dev mp, bp_store_dev bp, int one_row, int coop, hipStream_t st) {
   if (!nnodes) return DAFS_HIP_OK;
   // one accumulator row per wavefront in LDS: four wavefronts per workgroup while four rows fit, then two, then one
   const size_t budget = 124 * 1024;  // the kernel has 32 KB of static staging areas
@@ -1968,7 +2039,13 @@ int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_
   if (lds > budget) return DAFS_HIP_ETOOLONG;  // beyond ~31 000 columns
   int rc = lds_optin((const void*)k_node_avg, 0, lds, budget);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_node_avg, dim3((max_len + rows - 1) / rows, nnodes, 3), dim3(64 * rows), lds, st, d_nodes, mp, bp, row_cap);
+  // coop: four wavefronts per workgroup (the p_x / p_y rows keep a wavefront each, four rows per workgroup; a p_z row
+  // takes the whole workgroup, so the grid has a workgroup per row of the longest alignment)
+  if (coop && rows == 4) {
+    hipLaunchKernelGGL(k_node_avg, dim3(max_len, nnodes, 3), dim3(256), lds, st, d_nodes, mp, bp, row_cap, 1u);
+  } else {
+    hipLaunchKernelGGL(k_node_avg, dim3((max_len + rows - 1) / rows, nnodes, 3), dim3(64 * rows), lds, st, d_nodes, mp, bp, row_cap, 0u);
+  }
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, dd_params prm, uint32_t* d_ncbp, hipStream_t st) {
