@@ -295,7 +295,7 @@ int nodes_open(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const dafs_n
         auto nib = [](uint32_t L) { return ((size_t)L * (L + 1) / 2 + 7) / 8; };           // packed traceback codes, words
         // a fast folding DP: codes, the rows in flight (one per active lane), DD_CAP split rows per column
         auto fast = [&](uint32_t L) { return (nib(L) + dd_ring_words(L) + (size_t)DD_CAP * L) * 4; };
-        const size_t need_z = (((size_t)T + 15) / 16) * 4;                                   // packed alignment traceback
+        const size_t need_z = (size_t)dd_nwtab_words(L1, L2) * 4;                           // packed alignment traceback
         const uint32_t Lm = std::max(L1, L2);
         const size_t shared = (std::max(nib(L1), nib(L2)) + std::max(dd_ring_words(L1), dd_ring_words(L2)) + (size_t)DD_CAP * Lm) * 4;
         const size_t shared_g = (std::max(dd_ring_words(L1), dd_ring_words(L2)) + (size_t)DD_CAP * Lm) * 4;
@@ -350,6 +350,7 @@ int nodes_open(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const dafs_n
         nd.s_ys = span_any ? cv.take<float>((size_t)L2 * ((L2 + 63) & ~63u) + 64) : nullptr;
       }
       nd.env = cv.take<uint32_t>(2 * ((size_t)L1 + 1));
+      nd.env4 = cv.take<uint32_t>(2 * ((size_t)L1 + 130));
       nd.px_ptr = cv.take<uint32_t>((size_t)L1 + 2); nd.px_j = cv.take<uint32_t>(XX / 2 + 2);
       nd.py_ptr = cv.take<uint32_t>((size_t)L2 + 2); nd.py_l = cv.take<uint32_t>(YY / 2 + 2);
       nd.pz_ptr = cv.take<uint32_t>((size_t)L1 + 2); nd.pz_k = cv.take<uint32_t>(ZZ + 1);

@@ -36,6 +36,8 @@ struct dd_node {
                             // bit 5 alignment wave DP without input row buffers (second alignment too long for them),
                             // bit 6 span form of both folding DPs side by side (whole triangles in LDS; scores from s_xs / s_ys)
   uint32_t* env;      // 2*(L1+1)
+  uint32_t* env4;     // 2*(L1+130): the same envelope for the register-resident alignment DP -- {max(first,1), second} of row r at
+                      // index r + 64, the empty range {1, 0} for the 64 rows before row 1 and the 65 behind row L1 (no clamping, no selects)
   // sparse structure of p_x / p_y / p_z (> CUTOFF) and of the consensus base pairs
   int32_t *xmap, *ymap, *zmap;    // dense cell -> entry id (px / py / cz lists) or -1
   uint32_t *px_ptr, *px_j, *py_ptr, *py_l, *pz_ptr, *pz_k, *cz_ptr, *cz_k;
@@ -103,6 +105,10 @@ static inline __host__ __device__ uint32_t dd_ring_words(uint32_t L) {
 static inline __host__ __device__ uint32_t dd_span_nib_words(uint32_t L) { return (uint32_t)((((size_t)L * (L + 1) / 2 + 7) / 8 + 3) & ~(size_t)3); }
 static inline __host__ __device__ uint32_t dd_span_tri_words(uint32_t L) { return (uint32_t)(((size_t)L * (L + 1) / 2 + 3) & ~(size_t)3); }
 static inline __host__ __device__ uint32_t dd_span_words(uint32_t L) { return dd_span_nib_words(L) + dd_span_tri_words(L) + 2 * DD_CAP * (L + 1) + DD_CAP * L; }
+// packed traceback table of the alignment DP: two bits per cell, rows padded to whole 32-bit words (16 cells), so that the
+// bit position of a lane's cells within their word is the same in every row
+static inline __host__ __device__ uint32_t dd_nwtab_row_words(uint32_t L2) { return (L2 + 1 + 15) / 16; }
+static inline __host__ __device__ uint32_t dd_nwtab_words(uint32_t L1, uint32_t L2) { return (L1 + 1) * dd_nwtab_row_words(L2); }
 static const size_t kDdLdsBudget = 156 * 1024;  // dynamic LDS of k_dd_solve (the CU has 160 KB; ~2.2 KB is static)
 int dd_pack_launch(const dd_node* d_nodes, uint32_t nnodes, const uint32_t* d_off, uint32_t* d_out, hipStream_t st);
 int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size_t lds_bytes, bool split, uint32_t* d_paused, hipStream_t st);

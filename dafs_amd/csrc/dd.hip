@@ -219,25 +219,6 @@ __device__ bool nw_traceback(uint32_t L1, uint32_t L2, const uint8_t* tr, uint32
   return i == 0 && k == 0;
 }
 
-// the same walk over the two-bit table of nw_wave_reg<W, true>; row 0 / column 0 are implicit
-__device__ bool nw_traceback_packed(uint32_t L1, uint32_t L2, const uint32_t* tr_, uint32_t* al) {
-  const __attribute__((address_space(3))) uint32_t* tr = (const __attribute__((address_space(3))) uint32_t*)tr_;
-  const uint32_t W = L2 + 1;
-  int i = (int)L1, k = (int)L2;
-  uint32_t guard = L1 + L2 + 2;
-  while ((i > 0 || k > 0) && guard--) {
-    uint32_t t;
-    if (i == 0) t = 3;
-    else if (k == 0) t = 2;
-    else { const uint32_t q = (uint32_t)i * W + k; t = (tr[q >> 4] >> ((q & 15u) * 2)) & 3u; }
-    if (t == 1) { al[i - 1] = (uint32_t)(k - 1); --i; --k; }
-    else if (t == 2) { al[i - 1] = DD_NONE; --i; }
-    else if (t == 3) { --k; }
-    else return false;
-  }
-  return i == 0 && k == 0;
-}
-
 // ------------------------------------------------------------------------------------------
 // Single-wavefront forms of the two DPs, used inside the subgradient loop.  Lane t owns W
 // consecutive columns and keeps the previous row of its columns in LDS (P[c*64+lane]); rows are
@@ -669,13 +650,12 @@ __device__ void nuss_traceback_fast(uint32_t L, uint32_t* trb_, const uint8_t* t
 __device__ bool nw_traceback_wave(uint32_t L1, uint32_t L2, const uint32_t* tr_, uint32_t* al_, int lane) {
   DD_LDS const uint32_t* tr = (DD_LDS const uint32_t*)tr_;
   DD_GLB uint32_t* al = (DD_GLB uint32_t*)al_;
-  const uint32_t W = L2 + 1;
+  const uint32_t RW = dd_nwtab_row_words(L2);  // words per row of the table
   auto code = [&](int i, int k) -> uint32_t {  // 1 M, 2 X, 3 Y; 0 at (0,0), outside the grid and where the DP left no mark
     if (i < 0 || k < 0 || (i == 0 && k == 0)) return 0u;
     if (i == 0) return 3u;
     if (k == 0) return 2u;
-    const uint32_t q = (uint32_t)i * W + (uint32_t)k;
-    return (tr[q >> 4] >> ((q & 15u) * 2)) & 3u;
+    return (tr[(uint32_t)i * RW + ((uint32_t)k >> 4)] >> (((uint32_t)k & 15u) * 2)) & 3u;
   };
   int i = (int)L1, k = (int)L2;
   uint32_t guard = L1 + L2 + 2;
@@ -732,32 +712,36 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
   asm volatile("" : "+v"(ef), "+v"(es));
   if constexpr (TRL) {
     // The form with the packed table in LDS, straight-line: every cell is computed and then replaced by what its place in
-    // the grid says (outside the envelope: lowest(); column 0: 0; rows and columns outside the grid: unchanged), and the
-    // codes of the lane's W cells -- consecutive cells of one row -- go out together, as one 64-bit value shifted to its
-    // place: two ds_or instead of one per cell with its own address arithmetic.
+    // the grid says (outside the envelope: lowest(); column 0: 0; rows outside the grid: unchanged), and the codes of the
+    // lane's W cells -- consecutive cells of one row -- go out together, as one 64-bit value shifted to its place.  What a
+    // step needs besides its cells is kept small: env is the padded envelope (dd_node::env4: {max(first,1), second} of row
+    // r at r + 64, empty ranges around the grid: one 8-byte load, no clamping), the table's rows are whole words, so the
+    // lane's shift and word offset never change and its word pointer just moves down a row.
     typedef uint32_t v2u __attribute__((ext_vector_type(2)));
     const int k0 = lane * W;
     const bool lane0 = lane == 0;
+    const uint32_t RW = dd_nwtab_row_words(L2);
+    const uint32_t sh = ((uint32_t)k0 & 15u) * 2u;
+    int i = 1 - lane;                                                      // row of step 0
+    DD_GLB const v2u* envp = (DD_GLB const v2u*)env + (i + 1 + 64);        // envelope of row i + 1
+    DD_LDS uint32_t* word = tr_l + (int)RW * i + (k0 >> 4);                // the lane's cells in row i (never touched while i < 1)
+    DD_GLB const float* pnext = ps + (size_t)W * 64 + lane;                // inputs of step 1
+    DD_GLB const float* qnext = qs + (size_t)W * 64 + lane;
+    int lo = 1, hi = 0;
+    if (lane == 0) { const v2u e1 = ((DD_GLB const v2u*)env)[1 + 64]; lo = (int)e1.x; hi = (int)e1.y; }  // row 1
+    asm volatile("" : "+v"(lo), "+v"(hi));
     for (int s = 0; s < nsteps; ++s) {
-      const int i = s - lane + 1;
-      const bool rowv = i >= 1 && i <= (int)L1;
-      // envelope of the next row: one 8-byte load at a clamped row (rows outside 1..L1 get the empty range).  Issued
-      // BEFORE the prefetch of the next step's inputs: loads return in order, so the wait for it at the end of the step
-      // (vmcnt = the loads issued after it) leaves the prefetch in flight; the other way round every step would wait
-      // for its own prefetch.
-      const int in = i + 1;
-      const bool nrow = in >= 1 && in <= (int)L1;
-      const v2u ne = *(DD_GLB const v2u*)(env + 2 * (uint32_t)(in < 0 ? 0 : (in > (int)L1 ? (int)L1 : in)));
+      // the envelope of the next row first: loads return in order, so the wait for it at the end of the step leaves the
+      // prefetch of the next step's inputs in flight
+      const v2u ne = *envp;
       __builtin_amdgcn_sched_barrier(0);
       if (s + 1 < nsteps) {
 #pragma unroll
-        for (int c = 0; c < W; ++c) { np[c] = ps[((size_t)(s + 1) * W + c) * 64 + lane]; nq[c] = qs[((size_t)(s + 1) * W + c) * 64 + lane]; }
+        for (int c = 0; c < W; ++c) { np[c] = pnext[c * 64]; nq[c] = qnext[c * 64]; }
       }
       __builtin_amdgcn_sched_barrier(0);
+      const bool rowv = i >= 1 && i <= (int)L1;
       const float recv = wave_shr1(last);  // lane 0 owns column 0, which takes nothing from its left
-      // this row's cells of the envelope are the columns lo..hi (none when the lane is outside the rows)
-      const int lo = rowv ? (int)(ef > 1u ? ef : 1u) : 1, hi = rowv ? (int)es : 0;
-      const int kmax = rowv ? (int)L2 : -1;  // columns of the grid in this row
       float diag = leftprev;
       float left = recv;
       float v = 0.0f;
@@ -773,26 +757,24 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
         const bool m2 = v1 < left;
         const float v2 = m2 ? left : v1;
         const uint32_t t = m2 ? 3u : (m1 ? 2u : 1u);
-        const bool inside = k >= lo && k <= hi;
+        const bool inside = k >= lo && k <= hi;  // empty outside the rows of the grid
         v = inside ? v2 : -FLT_MAX;
-        if (c == 0) v = lane0 ? 0.0f : v;  // column 0
-        v = k <= kmax ? v : up;            // outside the grid: the cell keeps what it held (row 0 / the last row)
+        if (c == 0) v = lane0 ? 0.0f : v;        // column 0
+        v = rowv ? v : up;                       // rows outside the grid: the cell keeps what it held (row 0 / the last row)
         codes |= (unsigned long long)(inside ? t : 0u) << (2 * c);
         diag = up;
         P[c] = v;
         left = v;
       }
-      if (codes) {  // cells (i, k0 .. k0+W-1): bit position 2 q, q = i*T + k0
-        const uint32_t q = (uint32_t)i * T + (uint32_t)k0;
-        const uint32_t sh = (q & 15u) * 2u;
+      if (codes) {
         const unsigned long long w = codes << sh;
-        DD_LDS uint32_t* word = tr_l + (q >> 4);
         __hip_atomic_fetch_or(word, (uint32_t)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if ((uint32_t)(w >> 32)) __hip_atomic_fetch_or(word + 1, (uint32_t)(w >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       leftprev = recv;
       last = v;
-      ef = nrow ? ne.x : 1u; es = nrow ? ne.y : 0u;
+      lo = (int)ne.x; hi = (int)ne.y;
+      ++i; ++envp; word += RW; pnext += W * 64; qnext += W * 64;
 #pragma unroll
       for (int c = 0; c < W; ++c) { Pc[c] = np[c]; Qc[c] = nq[c]; }
     }
@@ -1632,7 +1614,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
   }
   // bit 0: packed alignment traceback; bit 1 / bit 2: the fast form of the x / y folding DP
   // (in-flight rows, candidate lists and packed traceback codes)
-  const uint32_t nzw = (uint32_t)(((size_t)(L1 + 1) * (L2 + 1) + 15) / 16), nxw = (uint32_t)(((size_t)L1 * (L1 + 1) / 2 + 7) / 8),
+  const uint32_t nzw = dd_nwtab_words(L1, L2), nxw = (uint32_t)(((size_t)L1 * (L1 + 1) / 2 + 7) / 8),
                  nyw = (uint32_t)(((size_t)L2 * (L2 + 1) / 2 + 7) / 8);
   uint32_t *trzp = nullptr, *trxp = nullptr, *tryp = nullptr;
   float *ringx = nullptr, *ringy = nullptr;
@@ -1682,6 +1664,12 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
       if (nd.s_ys) dd_fill_scores(true, L2, nd.p_y, nd.q_y, w_y, prm.th_s, nd.s_ys);
     }
     dd_fill_nw(L1, L2, nd.p_z, nd.q_z, nd.pz_s, nd.qz_s);
+    for (uint32_t r = tid; r < L1 + 130; r += nt) {  // the padded envelope (dd_node::env4)
+      const bool in = r >= 65 && r <= L1 + 64;        // rows 1 .. L1
+      const uint32_t ef = in ? nd.env[2 * (r - 64)] : 1u, es = in ? nd.env[2 * (r - 64) + 1] : 0u;
+      nd.env4[2 * r] = in ? (ef > 1u ? ef : 1u) : 1u;
+      nd.env4[2 * r + 1] = es;
+    }
   }
   __syncthreads();
   const int wave = (int)(tid >> 6), lane = (int)(tid & 63);
@@ -1769,7 +1757,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     if (wave == 2) {
       float sc;
       const unsigned long long tz0 = prm.stamps ? wall_clock64() : 0ull;
-      if (Wz <= DD_WNW && !nw_lean) sc = trzp ? nw_wave_fast<true>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, (uint8_t*)trzp, lane)
+      if (Wz <= DD_WNW && !nw_lean) sc = trzp ? nw_wave_fast<true>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env4, (uint8_t*)trzp, lane)
                                    : nw_wave_fast<false>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, trz, lane);
       else sc = nw_wave(L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, trz, Pz, Pbz, Qbz, lane);
       bool ok = true;
