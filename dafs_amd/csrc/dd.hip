@@ -1655,7 +1655,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     for (uint32_t e = tid; e < dd_span_tri_words(L2); e += nt) triy[e] = 0.0f;
   }
   if (!resume) {
-    nw_init_tr(L1, L2, trz);
+    if (!(trzp && Wz <= DD_WNW && !nw_lean)) nw_init_tr(L1, L2, trz);  // the byte table in HBM: only for alignments whose codes are not packed in LDS
     // sweep-order inputs of the three DPs, built once; the multiplier updates below keep them current
     if (!(prm.skip_xy && ncbp == 0)) {  // a node that leaves its foldings out (see fold_on below) needs no scores
       if (nd.s_x) dd_fill_scores(false, L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_x);  // only foldings with a register form keep one
