@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--th", type=float, default=0.01)
     ap.add_argument("--model", choices=("probcons", "contralign"), default="probcons", help="alignment model of the timed kernel")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-verify", action="store_true", help="tuning builds only (tools/build_exp.sh: kernels that stop after a sweep): skip the check of the "
+                    "timed launch against the oracle; the JSON line then says verified_pairs 0")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end wall-clock legs (warm driver run, cold CLI, forced-iteration DD run)")
     args = ap.parse_args()
     cfg_n, cfg_l = CONFIGS[args.config]
@@ -329,7 +331,7 @@ def main():
 
     # ---- the timed call path against the oracle: a strided sample of the last launch's outputs, bit for bit ----
     verified = 0
-    if rank == 0:
+    if rank == 0 and not args.no_verify:
         import oracle_lib
         orc = oracle_lib.load_oracle()
         o = sets[(nstep[0] - 1) % nsets]

@@ -56,6 +56,15 @@ struct cf_ctx {  // per-workgroup view
                          // null of the LDS address space is not the generic null, a pointer test after the cast is a trap
   const cf_params* P;    // score tables (LDS copy)
   bool free;             // no constraint string: every map entry is -1 and cum is all zero, the lookups are skipped
+  // Term pool of the current span (unconstrained sequences): the single-branch addends of every cell, evaluated by the
+  // whole workgroup before the cells fold them (cf_inside_terms / cf_outside_terms).  tbase[row] = start of the row's
+  // list in `pool`, or -1 when the pool was full (the cell then walks its partners itself); tcnt[row] = its length.
+  bool has_pool;
+  CF_LDS float* pool;
+  CF_LDS int* tbase;
+  CF_LDS int* tcnt;
+  CF_LDS int* ptop;
+  int pool_cap;
 };
 #define CF_RING 33
 
@@ -99,6 +108,131 @@ __device__ __forceinline__ float cf_single_nuc(const cf_ctx& c, int i, int j, in
 #define EXT_UNPAIRED (c.P->external_unpaired + 0.0f)
 
 // ---------------------------------------------------------------------------------------------
+// Single-branch addends, evaluated ahead of the chains that consume them.
+//
+// A cell's FC / FCo value is a chain sum = sum (+) term_1 (+) term_2 ... of up to 496 single-branch terms, and
+// Fast_LogPlusEquals is not associative: the chain is serial.  The terms are not: each is a handful of table lookups
+// that depend on the partner walk, not on the running sum.  Evaluated inside the chain's loop (one lane per cell,
+// round 1), every term cost four dependent LDS round trips and ~60 instructions of a wavefront that had ten lanes at
+// work -- ~1000 cycles per term, 86 % of the inside pass.  Here the whole workgroup evaluates the terms of a span
+// first: one lane per (cell, left offset l1), 32 lanes per cell, each lane writing the terms of its partners into the
+// cell's list in LDS in the order the chain takes them (the lists are laid out by a 32-lane prefix sum of the
+// partner counts, which are two table lookups, and placed in the pool by an atomic bump); after a barrier the cell's
+// lane folds the list with the sixteen-deep prefetch of cf_fold, so the chain sees one log-sum-exp per term and
+// nothing else.  Same terms, same order, same arithmetic: the values are bit-identical to the in-loop form, which
+// stays for constrained sequences and for cells whose list did not fit the pool.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cf_fc_load(const cf_ctx& c, const float* FC, int row, int col) {  // FC[row][col], recent spans from LDS
+  if (c.has_ring) return c.ring[((uint32_t)(col - row) % (uint32_t)CF_RING) * (uint32_t)(c.L + 1) + (uint32_t)row];
+  return FC[c.off[row] + col];
+}
+__device__ __forceinline__ int cf_half_prefix(int n, int hl, int* total) {  // inclusive prefix over the 32 lanes of a half-wave
+  int incl = n;
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    const int up = __shfl_up(incl, o, 32);
+    if (hl >= o) incl += up;
+  }
+  *total = __shfl(incl, 31, 32);
+  return incl;
+}
+// reserve room for a cell's list: lane 0 of the half bumps the pool, everyone gets the start (-1: no room)
+__device__ __forceinline__ int cf_pool_reserve(const cf_ctx& c, int row, int total, int hl, bool wanted) {
+  int base = -1;
+  if (hl == 0) {
+    if (wanted) {
+      if (total > 0) {
+        const int b = atomicAdd((int*)c.ptop, total);
+        if (b + total <= c.pool_cap) base = b;
+      } else {
+        base = 0;
+      }
+    }
+    c.tbase[row] = base;
+    c.tcnt[row] = total;
+  }
+  return __shfl(base, 0, 32);
+}
+
+// inside, span d: the terms of cf_inside_cell's single-branch loop (:3433-3528), p = i + l1 ascending, partners q descending
+__device__ void cf_inside_terms(const cf_ctx& c, int d, const float* FCi) {
+  const int L = c.L;
+  const int nitems = (L - d + 1) * 32;
+  const int hl = threadIdx.x & 31;
+  for (int item = threadIdx.x; item < nitems; item += blockDim.x) {
+    const int i = item >> 5, l1 = hl, j = i + d, p = i + l1;
+    const bool closing = (0 < i && j < L && cf_allow_paired(c, i, j + 1));
+    int n = 0, ehi = -1, sy = 4;
+    if (closing && l1 <= CF_MAX_SINGLE && p <= j) {
+      sy = c.s[p + 1];
+      if (sy != 4) {
+        const int q_min = max(p + 2, l1 + j - CF_MAX_SINGLE);
+        ehi = c.pcnt[sy * (L + 2) + j] - 1;                       // partners <= j
+        n = max(0, ehi + 1 - c.pcnt[sy * (L + 2) + q_min - 1]);   // ... that are >= q_min
+      }
+    }
+    int total;
+    const int incl = cf_half_prefix(n, hl, &total);
+    const int base = cf_pool_reserve(c, i, total, hl, closing);
+    if (base < 0 || n == 0) continue;
+    CF_LDS float* out = c.pool + base + incl - n;
+    const float score_helix = (i + 2 <= j ? cf_base_pair(c, i + 1, j) + cf_helix_stacking(c, i, j + 1) : 0.0f);
+    const float score_other = cf_junction_b(c, i, j);
+    const int* pl = c.plist + sy * L;
+    const int sp = c.s[p];
+    for (int k = 0; k < n; ++k) {
+      const int q = pl[ehi - k];
+      const float inner = cf_fc_load(c, FCi, p + 1, q - 1);
+      const int sq_ = c.s[q], sq1 = c.s[q + 1];
+      const float bp = 0.0f + c.P->base_pair[sy * 5 + sq_];
+      const float jb = 0.0f + c.P->helix_closing[sq_ * 5 + sy] + c.P->terminal_mismatch[((sq_ * 5 + sy) * 5 + sq1) * 5 + sp];
+      out[k] = (p == i && q == j) ? (score_helix + inner)
+                                  : (score_other + c.P->cache_single[(p - i) * 31 + (j - q)] + inner + bp + jb + cf_single_nuc(c, i, j, p, q));
+    }
+  }
+}
+
+// outside, span d: the single-branch sources of target (a, b = a + d) in cf_outside_cell's order, i = p-30 .. p ascending
+// (p = a - 1), partners j+1 descending
+__device__ void cf_outside_terms(const cf_ctx& c, int d, const float* FCo) {
+  const int L = c.L;
+  const int nitems = (L - d + 1) * 32;
+  const int hl = threadIdx.x & 31;
+  for (int item = threadIdx.x; item < nitems; item += blockDim.x) {
+    const int a = item >> 5, b = a + d, p = a - 1, q = b + 1;
+    const int i = p - CF_MAX_SINGLE + hl, l1 = p - i;
+    const bool pair_ok = (0 < a && b < L && cf_allow_paired(c, a, b + 1));
+    int n = 0, ehi = -1, sy = 4;
+    if (pair_ok && hl <= CF_MAX_SINGLE && i >= 1) {
+      sy = c.s[i];
+      if (sy != 4) {
+        const int jmax = min(L - 1, q + CF_MAX_SINGLE - l1);
+        const int lowest = (i == p) ? q + 2 : q + 1;
+        ehi = c.pcnt[sy * (L + 2) + jmax + 1] - 1;
+        n = max(0, ehi + 1 - c.pcnt[sy * (L + 2) + lowest - 1]);
+      }
+    }
+    int total;
+    const int incl = cf_half_prefix(n, hl, &total);
+    const int base = cf_pool_reserve(c, a, total, hl, pair_ok);
+    if (base < 0 || n == 0) continue;
+    CF_LDS float* out = c.pool + base + incl - n;
+    const float bp_pq = cf_base_pair(c, p + 1, q), jb_qp = cf_junction_b(c, q, p);
+    const int* pl = c.plist + sy * L;
+    const int si1 = c.s[i + 1];
+    for (int k = 0; k < n; ++k) {
+      const int j1 = pl[ehi - k];
+      const int j = j1 - 1, l2 = j - q;
+      const float src = cf_fc_load(c, FCo, i, j);
+      const int sj1 = c.s[j1], sj = c.s[j];
+      const float jb_ij = 0.0f + c.P->helix_closing[sy * 5 + sj1] + c.P->terminal_mismatch[((sy * 5 + sj1) * 5 + si1) * 5 + sj];
+      const float score_other = src + jb_ij;
+      out[k] = score_other + c.P->cache_single[l1 * 31 + l2] + bp_pq + jb_qp + cf_single_nuc(c, i, j, p, q);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // inside cell (i,j), InferenceEngine.ipp:3392-3688
 // ---------------------------------------------------------------------------------------------
 // constraint part of allow_paired for a symbol-compatible pair (a < q)
@@ -106,10 +240,6 @@ __device__ __forceinline__ bool cf_map_ok(const cf_ctx& c, int a, int q) {
   if (c.free) return true;
   const int ma = c.map[a], mq = c.map[q];
   return (ma == -1 || ma == q) && (mq == -1 || mq == a);
-}
-__device__ __forceinline__ float cf_fc_load(const cf_ctx& c, const float* FC, int row, int col) {  // FC[row][col], recent spans from LDS
-  if (c.has_ring) return c.ring[((uint32_t)(col - row) % (uint32_t)CF_RING) * (uint32_t)(c.L + 1) + (uint32_t)row];
-  return FC[c.off[row] + col];
 }
 
 // acc (+)= term(0) (+) term(1) ... (+) term(n-1), in that order (Fast_LogPlusEquals is not associative).
@@ -157,7 +287,12 @@ __device__ void cf_inside_cell(const cf_ctx& c, int i, int j, float* FCi, float*
     if (cf_all_unpaired(c, i, j)) sum = cf_lpe(sum, cf_hairpin(c, i, j));
     const float score_helix = (i + 2 <= j ? cf_base_pair(c, i + 1, j) + cf_helix_stacking(c, i, j + 1) : 0.0f);
     const float score_other = cf_junction_b(c, i, j);
-    const int pmax = min(i + CF_MAX_SINGLE, j);
+    const bool pooled = c.has_pool && c.free && c.tbase[i] >= 0;
+    if (pooled) {  // the terms of the loop below, already evaluated (cf_inside_terms)
+      CF_LDS const float* tl = c.pool + c.tbase[i];
+      sum = cf_fold(sum, c.tcnt[i], [&](int u) { return tl[u]; });
+    }
+    const int pmax = pooled ? i - 1 : min(i + CF_MAX_SINGLE, j);
     for (int p = i; p <= pmax; p++) {
       if (p > i && !cf_unpaired_pos(c, p)) break;
       const int q_min = max(p + 2, p - i + j - CF_MAX_SINGLE);
@@ -255,12 +390,17 @@ __device__ void cf_outside_cell(const cf_ctx& c, int a, int b, const float* FCi,
       fco = cf_lpe(fco, temp + F5i[p]);
     }
     const float bp_pq = cf_base_pair(c, p + 1, q), jb_qp = cf_junction_b(c, q, p);  // the same two addends in every single-branch term
-    for (int i = max(1, p - CF_MAX_SINGLE); i <= p; i++) {
+    const bool pooled = c.has_pool && c.free && c.tbase[a] >= 0;
+    if (pooled) {  // the partner terms of the loop below, already evaluated (cf_outside_terms); what is left is i == p's tail
+      CF_LDS const float* tl = c.pool + c.tbase[a];
+      fco = cf_fold(fco, c.tcnt[a], [&](int u) { return tl[u]; });
+    }
+    for (int i = pooled ? max(1, p) : max(1, p - CF_MAX_SINGLE); i <= p; i++) {
       const int l1 = p - i;
       if (l1 > 0 && !cf_all_unpaired(c, i, p)) continue;
       const int jmax = min(L - 1, q + CF_MAX_SINGLE - l1);
       const int sy = c.s[i];
-      if (sy != 4) {
+      if (sy != 4 && !pooled) {
         // sources (i,j) close the pair (i, j+1): walk the partners of i from jmax+1 down to q+2 (q+1 is the
         // (p,q) / bulge-free slot handled below for i == p, and a normal source for i < p)
         const int* pl = c.plist + sy * L;
@@ -403,7 +543,10 @@ __device__ void cf_bind(cf_ctx& c, int L, int* ints, float* ring, const cf_param
   c.s = s; c.map = map; c.cum = cum; c.off = off; c.plist = plist; c.pcnt = pcnt; c.P = P;
 }
 
-__global__ __launch_bounds__(CF_FOLD_THREADS) void k_contrafold(cf_batch B, int use_ring) {
+// pool_floats: capacity of the term pool in the dynamic LDS behind the ring (0 = no pool); cell_waves: the cells of a span
+// are dealt to this many wavefronts (the chains are latency-bound and every wavefront they are spread over adds its
+// whole instruction stream to the SIMD's issue load), while the term evaluation uses all of them
+__global__ __launch_bounds__(CF_FOLD_THREADS) void k_contrafold(cf_batch B, int use_ring, int pool_floats, int cell_waves) {
   CF_TABLES_INIT();
   __shared__ cf_params sP;
   __shared__ float s_terms[CF_FOLD_THREADS];
@@ -416,12 +559,24 @@ __global__ __launch_bounds__(CF_FOLD_THREADS) void k_contrafold(cf_batch B, int 
   const cf_seq sq = B.seqs[x];
   const int L = (int)sq.len;
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int cid = (tid & 63) * (nt >> 6) + (tid >> 6);  // this thread's place in a span (see CF_FOLD_THREADS)
+  const int cw = min(cell_waves, nt >> 6);
+  const int cnt_ = cw * 64;                                            // threads that own cells
+  const int cid = (tid >> 6) < cw ? (tid & 63) * cw + (tid >> 6) : nt;  // this thread's place in a span (see CF_FOLD_THREADS); nt = none
   extern __shared__ int s_ints[];
   float* ring = use_ring ? (float*)(s_ints + CF_INTS(L)) : nullptr;
   cf_ctx c;
   cf_bind(c, L, s_ints, ring, &sP);
   c.free = !sq.has_constraint;
+  {
+    int* after = s_ints + CF_INTS(L) + (use_ring ? CF_RING * (L + 1) : 0);
+    c.has_pool = pool_floats > 0 && c.free;
+    c.tbase = (CF_LDS int*)after;
+    c.tcnt = (CF_LDS int*)(after + (L + 1));
+    c.ptop = (CF_LDS int*)(after + 2 * (L + 1));
+    c.pool = (CF_LDS float*)(after + 2 * (L + 1) + 1);
+    c.pool_cap = pool_floats;
+    if (tid == 0 && c.has_pool) *c.ptop = 0;
+  }
   int* s = (int*)c.s; int* map = (int*)c.map; int* cum = (int*)c.cum; int* off = (int*)c.off;
   int* plist = (int*)c.plist; int* pcnt = (int*)c.pcnt;
   float* F = B.fws + sq.fws_off;
@@ -468,7 +623,16 @@ __global__ __launch_bounds__(CF_FOLD_THREADS) void k_contrafold(cf_batch B, int 
   CF_STAMP(0);
   // ---- inside: span ascending
   for (int d = 0; d <= L; ++d) {
-    for (int i = cid; i + d <= L; i += nt) cf_inside_cell(c, i, i + d, FCi, FMi, FM1i);
+    const bool terms = c.has_pool && d >= 2;  // shorter spans have no single-branch term
+    if (terms) {
+      cf_inside_terms(c, d, FCi);
+      __syncthreads();
+    } else if (c.has_pool) {
+      for (int i = tid; i + d <= L; i += nt) c.tbase[i] = -1;
+      __syncthreads();
+    }
+    if (tid == 0 && c.has_pool) *c.ptop = 0;  // every bump of this span is behind the barrier, the next span's in front of the one below
+    for (int i = cid; i + d <= L; i += cnt_) cf_inside_cell(c, i, i + d, FCi, FMi, FM1i);
     __syncthreads();
   }
   CF_STAMP(1);
@@ -510,7 +674,7 @@ __global__ __launch_bounds__(CF_FOLD_THREADS) void k_contrafold(cf_batch B, int 
   __syncthreads();
   for (int j = L; j >= 1; --j) {
     const float f5oj = F5o[j];
-    for (int k = cid; k < j; k += nt) {
+    for (int k = cid; k < j; k += cnt_) {
       float v = F5o[k];
       if (k == j - 1 && cf_unpaired_pos(c, j)) v = cf_lpe(v, f5oj + EXT_UNPAIRED);
       if (cf_allow_paired(c, k + 1, j)) {
@@ -524,7 +688,12 @@ __global__ __launch_bounds__(CF_FOLD_THREADS) void k_contrafold(cf_batch B, int 
   CF_STAMP(3);
   // main sweep: span descending
   for (int d = L; d >= 0; --d) {
-    for (int a = cid; a + d <= L; a += nt) cf_outside_cell(c, a, a + d, FCi, FMi, FM1i, F5i, F5o, FCo, FMo, FM1o, FM2o);
+    if (c.has_pool) {
+      cf_outside_terms(c, d, FCo);
+      __syncthreads();
+    }
+    if (tid == 0 && c.has_pool) *c.ptop = 0;
+    for (int a = cid; a + d <= L; a += cnt_) cf_outside_cell(c, a, a + d, FCi, FMi, FM1i, F5i, F5o, FCo, FMo, FM1o, FM2o);
     __syncthreads();
   }
   CF_STAMP(4);
@@ -605,16 +774,36 @@ int contrafold_launch(const cf_batch& B, uint32_t nseq, uint32_t max_len, hipStr
   const size_t budget = 100 * 1024;  // dynamic LDS (static: score tables ~11 KB)
   if (ints > budget) return DAFS_HIP_ETOOLONG;
   const int use_ring = ints + ring <= budget && !getenv("DAFS_HIP_CF_NORING");  // the env switch is a tuning aid
-  const size_t lds = ints + (use_ring ? ring : 0);
+  size_t lds = ints + (use_ring ? ring : 0);
+  // the term pool takes what is left of the CU's LDS behind the kernel's static tables (at least two full lists, or none)
+  int pool_floats = 0;
+  size_t stat = 28 * 1024;  // static LDS of k_contrafold (score tables, log-sum-exp tables)
+  const size_t total = 160 * 1024 - 512;
+  {
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, (const void*)k_contrafold) == hipSuccess) stat = at.sharedSizeBytes;
+    else (void)hipGetLastError();
+    const size_t fixed = lds + (2 * ((size_t)max_len + 1) + 1) * sizeof(int);
+    if (use_ring && !getenv("DAFS_HIP_CF_NOPOOL") && stat + fixed + 2 * 496 * sizeof(float) <= total) {
+      pool_floats = (int)((total - stat - fixed) / sizeof(float));
+      lds = fixed + (size_t)pool_floats * sizeof(float);
+    }
+  }
+  int cell_waves = 8;
+  if (const char* e = getenv("DAFS_HIP_CF_CELL_WAVES")) {  // tuning aid
+    const int v = atoi(e);
+    if (v >= 1 && v <= CF_FOLD_THREADS / 64) cell_waves = v;
+  }
+  const size_t optin = total - stat;  // the most dynamic LDS a launch may ask for
   static bool attr_a[16] = {false}, attr_b[16] = {false};
-  if (!lds_optin_once((const void*)k_contrafold, (int)budget, attr_a)) return DAFS_HIP_ELAUNCH;
+  if (!lds_optin_once((const void*)k_contrafold, (int)optin, attr_a)) return DAFS_HIP_ELAUNCH;
   if (!lds_optin_once((const void*)k_contrafold_posterior, (int)budget, attr_b)) return DAFS_HIP_ELAUNCH;
   int fold_threads = CF_FOLD_THREADS;
   if (const char* e = getenv("DAFS_HIP_CF_THREADS")) {  // tuning aid: 64..1024 in whole wavefronts
     const int v = atoi(e);
     if (v >= 64 && v <= CF_FOLD_THREADS && v % 64 == 0) fold_threads = v;
   }
-  hipLaunchKernelGGL(k_contrafold, dim3(nseq), dim3(fold_threads), lds, st, B, use_ring);
+  hipLaunchKernelGGL(k_contrafold, dim3(nseq), dim3(fold_threads), lds, st, B, use_ring, pool_floats, cell_waves);
   if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
   hipLaunchKernelGGL(k_contrafold_posterior, dim3(max_len + 1, nseq), dim3(CF_THREADS), ints, st, B);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;

@@ -110,10 +110,16 @@ __device__ __forceinline__ bool pair_finish(const Args& a, float* __restrict__ s
       int dtr = dgtr, ltr = rtr, run = rcnt;
       float pp[WR];
       post(sv, pp);  // the model's posteriors of the WR cells, table reads batched
-      if (s + 1 < nsteps) {
+      {  // private slots: unguarded (cells outside the grid are ignored below); the last step refetches its own
+        const float* __restrict__ slab_n = slab_s + (s + 1 < nsteps ? W * 64 : 0);
 #pragma unroll
-        for (int c = 0; c < WR; ++c) sv[c] = slab_s[(W + c) * 64 + lane];  // private slots: unguarded (cells outside the grid are ignored below)
+        for (int c = 0; c < WR; ++c) sv[c] = slab_n[c * 64 + lane];
       }
+      // One straight-line block for the WR cells (the posteriors' polynomials, the similarity DP and the counts as
+      // selects: five independent chains the scheduler can interleave), then the rare appends.  Written as per-cell
+      // if / else, every cell becomes a handful of basic blocks and its polynomial waits for the cell before it.
+      bool ent[WR];
+      int runa[WR];  // entries of the row up to and including cell c
 #pragma unroll
       for (int c = 0; c < WR; ++c) {
         const int j = j0 + c;
@@ -122,38 +128,48 @@ __device__ __forceinline__ bool pair_finish(const Args& a, float* __restrict__ s
         // wrapper (>= th keeps) then adapter (> th keeps): align.cpp:69-78
         const float p = pp[c];
         const bool entry = inner && (p >= th) && (p > th);
-        if (dense) {
-          slab_s[c * 64 + lane] = entry ? p : 0.0f;
-        } else if (entry) {
-          if (3 * nrec + 3 <= list_cap) {
-            float* __restrict__ r = list + (size_t)(3 * nrec) * 64 + lane;
-            r[0] = p;
-            r[64] = __int_as_float((i - 1) | (c << 16));
-            r[128] = __int_as_float(run | (colcnt[c] << 16));
-            ++nrec;
-          } else {
-            ovf = true;
-          }
-        }
-        // calculate_similarity_score, dafs.cpp:720-760
+        ent[c] = entry;
+        if (dense) slab_s[c * 64 + lane] = entry ? p : 0.0f;
+        // calculate_similarity_score, dafs.cpp:720-760: an entry starts from the diagonal (dp = ddp + p) and is replaced
+        // by the left, then the upper neighbour where that is strictly larger; a non-entry starts from the left one.
+        // Every dp is >= 0, so a start of -1 for a non-entry always takes the left neighbour.
         const float udp = pdp[c];
         const int utr = ptr[c];
-        float dp;
-        int tr;
-        if (entry) {
-          dp = ddp + p; tr = dtr + 1;
-          if (dp < ldp) { dp = ldp; tr = ltr + 1; }
-          if (dp < udp) { dp = udp; tr = utr + 1; }
-        } else {
-          dp = ldp; tr = ltr + 1;
-          if (dp < udp) { dp = udp; tr = utr + 1; }
-        }
+        const float dpe = entry ? ddp + p : -1.0f;
+        const bool fl = dpe < ldp;
+        float dp = fl ? ldp : dpe;
+        int tr = fl ? ltr : dtr;
+        const bool fu = dp < udp;
+        dp = fu ? udp : dp;
+        tr = (fu ? utr : tr) + 1;
         if (!inner) { dp = 0.0f; tr = 0; }
         ddp = udp; dtr = utr;
         pdp[c] = dp; ptr[c] = tr;
         ldp = dp; ltr = tr;
         run += entry ? 1 : 0;
         colcnt[c] += entry ? 1 : 0;
+        runa[c] = run;
+      }
+      if (!dense) {
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < WR; ++c) any = any || ent[c];
+        if (any) {
+#pragma unroll
+          for (int c = 0; c < WR; ++c) {
+            if (ent[c]) {
+              if (3 * nrec + 3 <= list_cap) {
+                float* __restrict__ r = list + (size_t)(3 * nrec) * 64 + lane;
+                r[0] = pp[c];
+                r[64] = __int_as_float((i - 1) | (c << 16));
+                r[128] = __int_as_float((runa[c] - 1) | ((colcnt[c] - 1) << 16));  // positions before this entry
+                ++nrec;
+              } else {
+                ovf = true;
+              }
+            }
+          }
+        }
       }
       dgdp = rdp; dgtr = rtr;
       lastdp = ldp; lasttr = ltr; lastcnt = run;

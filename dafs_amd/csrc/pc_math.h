@@ -65,7 +65,7 @@ struct pc_tables {
   float4 lq[16];       // the same cubics in the slot order of pc_log_add_n, for arguments scaled by 32: one ds_read_b128 per LOG_ADD
   double2 exp_hi[8];   // k4,k3 of the EXP quartics, index = clamp(exponent(|x|) + 2, 0, 6); [6] = zero
   double2 exp_mid[8];  // k2,k1
-  double exp_lo[8];    // k0
+  double2 exp_lo[8];   // k0 (and a pad: the three tables share one byte offset, 16 * piece)
 };
 
 __device__ __forceinline__ void pc_tables_init(pc_tables* t, int tid) {
@@ -87,7 +87,7 @@ __device__ __forceinline__ void pc_tables_init(pc_tables* t, int tid) {
       const bool z = k >= 6;
       t->exp_hi[k] = z ? make_double2(0.0, 0.0) : make_double2(e[k][0], e[k][1]);
       t->exp_mid[k] = z ? make_double2(0.0, 0.0) : make_double2(e[k][2], e[k][3]);
-      t->exp_lo[k] = z ? 0.0 : e[k][4];
+      t->exp_lo[k] = make_double2(z ? 0.0 : e[k][4], 0.0);
     }
   }
 }
@@ -192,16 +192,16 @@ __device__ __forceinline__ void pc_exp_chunk(const pc_tables* t, const float (&x
   double c[N];
 #pragma unroll
   for (int n = 0; n < N; ++n) {
-    const float a = fmaxf(-xf[OFF + n], 1.0e-30f);  // |x|, away from 0 so that the exponent is defined
-    int e;
-    (void)frexpf(a, &e);                            // a = m * 2^e, m in [0.5, 1)
-    // x > -0.5 <=> a < 0.5 <=> e <= -1 ; -1 < x <= -0.5 <=> e == 0 ; ... ; -16 < x <= -8 <=> e == 4
-    // (piece boundaries are closed on the lower side: x <= -0.5 leaves piece 0, matching a >= 0.5 <=> e >= 0)
-    piece[n] = min(max(e + 1, 0), 6);
+    // |x| = m * 2^e, m in [0.5, 1):  x > -0.5 <=> e <= -1 ; -1 < x <= -0.5 <=> e == 0 ; ... ; -16 < x <= -8 <=> e == 4
+    // (piece boundaries are closed on the lower side: x <= -0.5 leaves piece 0, matching |x| >= 0.5 <=> e >= 0), so the
+    // piece is clamp(e + 1, 0, 6), and e + 1 is the biased exponent field minus 125 (zero and denormals: field 0 -> piece 0).
+    // One bit-field extract, one add, one median instead of frexp and its guards.
+    const int e8 = (__float_as_int(xf[OFF + n]) >> 23) & 0xFF;
+    piece[n] = min(max(e8 - 125, 0), 6);
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int n = 0; n < N; ++n) { h[n] = t->exp_hi[piece[n]]; m[n] = t->exp_mid[piece[n]]; c[n] = t->exp_lo[piece[n]]; }
+  for (int n = 0; n < N; ++n) { h[n] = t->exp_hi[piece[n]]; m[n] = t->exp_mid[piece[n]]; c[n] = t->exp_lo[piece[n]].x; }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int n = 0; n < N; ++n) {
