@@ -137,8 +137,8 @@ int run_job(dafs_hip_ctx* c, const fold_job& job, const uint8_t* d_codes, const 
   if (!rc && B.stamps) {
     unsigned long long h[8] = {0};
     if (!hip_check(hipMemcpy(h, B.stamps, sizeof h, hipMemcpyDeviceToHost)))
-      fprintf(stderr, "k_contrafold block 0 (us): inside %.0f | F5i %.0f | F5o %.0f | outside %.0f\n", (h[1] - h[0]) / 100.0, (h[2] - h[1]) / 100.0,
-              (h[3] - h[2]) / 100.0, (h[4] - h[3]) / 100.0);
+      fprintf(stderr, "k_contrafold block 0 (us): inside %.0f (terms %.0f) | F5i %.0f | F5o %.0f | outside %.0f (terms %.0f)\n", (h[1] - h[0]) / 100.0,
+              h[5] / 100.0, (h[2] - h[1]) / 100.0, (h[3] - h[2]) / 100.0, (h[4] - h[3]) / 100.0, h[6] / 100.0);
   }
   return rc;
 }

@@ -59,13 +59,20 @@ struct cf_ctx {  // per-workgroup view
   // Term pool of the current span (unconstrained sequences): the single-branch addends of every cell, evaluated by the
   // whole workgroup before the cells fold them (cf_inside_terms / cf_outside_terms).  tbase[row] = start of the row's
   // list in `pool`, or -1 when the pool was full (the cell then walks its partners itself); tcnt[row] = its length.
+  // Two buffers when there is room (pool_bufs == 2): the wavefronts that own no cell evaluate the terms of the next
+  // span into one while the cells of this span fold the other (a span's terms only read FC values two or more spans
+  // away, so they do not wait for this span).  `cur` = the buffer the cells read.
   bool has_pool;
   CF_LDS float* pool;
   CF_LDS int* tbase;
   CF_LDS int* tcnt;
   CF_LDS int* ptop;
-  int pool_cap;
+  int pool_cap;   // floats per buffer
+  int cur;
 };
+__device__ __forceinline__ CF_LDS int* cf_tbase(const cf_ctx& c, int buf) { return c.tbase + buf * (c.L + 1); }
+__device__ __forceinline__ CF_LDS int* cf_tcnt(const cf_ctx& c, int buf) { return c.tcnt + buf * (c.L + 1); }
+__device__ __forceinline__ CF_LDS float* cf_pool(const cf_ctx& c, int buf) { return c.pool + (size_t)buf * c.pool_cap; }
 #define CF_RING 33
 
 __device__ __forceinline__ bool cf_comp(int a, int b) {  // AU, GU, CG (InferenceEngine ctor)
@@ -137,29 +144,30 @@ __device__ __forceinline__ int cf_half_prefix(int n, int hl, int* total) {  // i
   return incl;
 }
 // reserve room for a cell's list: lane 0 of the half bumps the pool, everyone gets the start (-1: no room)
-__device__ __forceinline__ int cf_pool_reserve(const cf_ctx& c, int row, int total, int hl, bool wanted) {
+__device__ __forceinline__ int cf_pool_reserve(const cf_ctx& c, int buf, int row, int total, int hl, bool wanted) {
   int base = -1;
   if (hl == 0) {
     if (wanted) {
       if (total > 0) {
-        const int b = atomicAdd((int*)c.ptop, total);
+        const int b = atomicAdd((int*)(c.ptop + buf), total);
         if (b + total <= c.pool_cap) base = b;
       } else {
         base = 0;
       }
     }
-    c.tbase[row] = base;
-    c.tcnt[row] = total;
+    cf_tbase(c, buf)[row] = base;
+    cf_tcnt(c, buf)[row] = total;
   }
   return __shfl(base, 0, 32);
 }
 
 // inside, span d: the terms of cf_inside_cell's single-branch loop (:3433-3528), p = i + l1 ascending, partners q descending
-__device__ void cf_inside_terms(const cf_ctx& c, int d, const float* FCi) {
+// (threads t0 .. t0+tn-1 of the workgroup take part: whole wavefronts)
+__device__ void cf_inside_terms(const cf_ctx& c, int d, const float* FCi, int buf, int t0, int tn) {
   const int L = c.L;
   const int nitems = (L - d + 1) * 32;
   const int hl = threadIdx.x & 31;
-  for (int item = threadIdx.x; item < nitems; item += blockDim.x) {
+  for (int item = (int)threadIdx.x - t0; item < nitems; item += tn) {
     const int i = item >> 5, l1 = hl, j = i + d, p = i + l1;
     const bool closing = (0 < i && j < L && cf_allow_paired(c, i, j + 1));
     int n = 0, ehi = -1, sy = 4;
@@ -173,9 +181,9 @@ __device__ void cf_inside_terms(const cf_ctx& c, int d, const float* FCi) {
     }
     int total;
     const int incl = cf_half_prefix(n, hl, &total);
-    const int base = cf_pool_reserve(c, i, total, hl, closing);
+    const int base = cf_pool_reserve(c, buf, i, total, hl, closing);
     if (base < 0 || n == 0) continue;
-    CF_LDS float* out = c.pool + base + incl - n;
+    CF_LDS float* out = cf_pool(c, buf) + base + incl - n;
     const float score_helix = (i + 2 <= j ? cf_base_pair(c, i + 1, j) + cf_helix_stacking(c, i, j + 1) : 0.0f);
     const float score_other = cf_junction_b(c, i, j);
     const int* pl = c.plist + sy * L;
@@ -194,11 +202,11 @@ __device__ void cf_inside_terms(const cf_ctx& c, int d, const float* FCi) {
 
 // outside, span d: the single-branch sources of target (a, b = a + d) in cf_outside_cell's order, i = p-30 .. p ascending
 // (p = a - 1), partners j+1 descending
-__device__ void cf_outside_terms(const cf_ctx& c, int d, const float* FCo) {
+__device__ void cf_outside_terms(const cf_ctx& c, int d, const float* FCo, int buf, int t0, int tn) {
   const int L = c.L;
   const int nitems = (L - d + 1) * 32;
   const int hl = threadIdx.x & 31;
-  for (int item = threadIdx.x; item < nitems; item += blockDim.x) {
+  for (int item = (int)threadIdx.x - t0; item < nitems; item += tn) {
     const int a = item >> 5, b = a + d, p = a - 1, q = b + 1;
     const int i = p - CF_MAX_SINGLE + hl, l1 = p - i;
     const bool pair_ok = (0 < a && b < L && cf_allow_paired(c, a, b + 1));
@@ -214,9 +222,9 @@ __device__ void cf_outside_terms(const cf_ctx& c, int d, const float* FCo) {
     }
     int total;
     const int incl = cf_half_prefix(n, hl, &total);
-    const int base = cf_pool_reserve(c, a, total, hl, pair_ok);
+    const int base = cf_pool_reserve(c, buf, a, total, hl, pair_ok);
     if (base < 0 || n == 0) continue;
-    CF_LDS float* out = c.pool + base + incl - n;
+    CF_LDS float* out = cf_pool(c, buf) + base + incl - n;
     const float bp_pq = cf_base_pair(c, p + 1, q), jb_qp = cf_junction_b(c, q, p);
     const int* pl = c.plist + sy * L;
     const int si1 = c.s[i + 1];
@@ -287,10 +295,10 @@ __device__ void cf_inside_cell(const cf_ctx& c, int i, int j, float* FCi, float*
     if (cf_all_unpaired(c, i, j)) sum = cf_lpe(sum, cf_hairpin(c, i, j));
     const float score_helix = (i + 2 <= j ? cf_base_pair(c, i + 1, j) + cf_helix_stacking(c, i, j + 1) : 0.0f);
     const float score_other = cf_junction_b(c, i, j);
-    const bool pooled = c.has_pool && c.free && c.tbase[i] >= 0;
+    const bool pooled = c.has_pool && c.free && cf_tbase(c, c.cur)[i] >= 0;
     if (pooled) {  // the terms of the loop below, already evaluated (cf_inside_terms)
-      CF_LDS const float* tl = c.pool + c.tbase[i];
-      sum = cf_fold(sum, c.tcnt[i], [&](int u) { return tl[u]; });
+      CF_LDS const float* tl = cf_pool(c, c.cur) + cf_tbase(c, c.cur)[i];
+      sum = cf_fold(sum, cf_tcnt(c, c.cur)[i], [&](int u) { return tl[u]; });
     }
     const int pmax = pooled ? i - 1 : min(i + CF_MAX_SINGLE, j);
     for (int p = i; p <= pmax; p++) {
@@ -390,10 +398,10 @@ __device__ void cf_outside_cell(const cf_ctx& c, int a, int b, const float* FCi,
       fco = cf_lpe(fco, temp + F5i[p]);
     }
     const float bp_pq = cf_base_pair(c, p + 1, q), jb_qp = cf_junction_b(c, q, p);  // the same two addends in every single-branch term
-    const bool pooled = c.has_pool && c.free && c.tbase[a] >= 0;
+    const bool pooled = c.has_pool && c.free && cf_tbase(c, c.cur)[a] >= 0;
     if (pooled) {  // the partner terms of the loop below, already evaluated (cf_outside_terms); what is left is i == p's tail
-      CF_LDS const float* tl = c.pool + c.tbase[a];
-      fco = cf_fold(fco, c.tcnt[a], [&](int u) { return tl[u]; });
+      CF_LDS const float* tl = cf_pool(c, c.cur) + cf_tbase(c, c.cur)[a];
+      fco = cf_fold(fco, cf_tcnt(c, c.cur)[a], [&](int u) { return tl[u]; });
     }
     for (int i = pooled ? max(1, p) : max(1, p - CF_MAX_SINGLE); i <= p; i++) {
       const int l1 = p - i;
@@ -546,7 +554,9 @@ __device__ void cf_bind(cf_ctx& c, int L, int* ints, float* ring, const cf_param
 // pool_floats: capacity of the term pool in the dynamic LDS behind the ring (0 = no pool); cell_waves: the cells of a span
 // are dealt to this many wavefronts (the chains are latency-bound and every wavefront they are spread over adds its
 // whole instruction stream to the SIMD's issue load), while the term evaluation uses all of them
-__global__ __launch_bounds__(CF_FOLD_THREADS) void k_contrafold(cf_batch B, int use_ring, int pool_floats, int cell_waves) {
+// pool_bufs: 1 = one pool, filled by every wavefront before the cells of a span run; 2 = two halves, the next span's terms
+// evaluated by the wavefronts without cells while this span's cells run
+__global__ __launch_bounds__(CF_FOLD_THREADS) void k_contrafold(cf_batch B, int use_ring, int pool_floats, int cell_waves, int pool_bufs) {
   CF_TABLES_INIT();
   __shared__ cf_params sP;
   __shared__ float s_terms[CF_FOLD_THREADS];
@@ -571,12 +581,15 @@ __global__ __launch_bounds__(CF_FOLD_THREADS) void k_contrafold(cf_batch B, int 
     int* after = s_ints + CF_INTS(L) + (use_ring ? CF_RING * (L + 1) : 0);
     c.has_pool = pool_floats > 0 && c.free;
     c.tbase = (CF_LDS int*)after;
-    c.tcnt = (CF_LDS int*)(after + (L + 1));
-    c.ptop = (CF_LDS int*)(after + 2 * (L + 1));
-    c.pool = (CF_LDS float*)(after + 2 * (L + 1) + 1);
-    c.pool_cap = pool_floats;
-    if (tid == 0 && c.has_pool) *c.ptop = 0;
+    c.tcnt = (CF_LDS int*)(after + 2 * (L + 1));
+    c.ptop = (CF_LDS int*)(after + 4 * (L + 1));
+    c.pool = (CF_LDS float*)(after + 4 * (L + 1) + 2);
+    c.pool_cap = pool_floats / pool_bufs;
+    c.cur = 0;
+    if (tid == 0 && c.has_pool) c.ptop[0] = c.ptop[1] = 0;
   }
+  const bool overlap = c.has_pool && pool_bufs == 2 && cnt_ < nt;  // wavefronts left over for the terms
+  const int tw0 = overlap ? cnt_ : 0, twn = nt - tw0;               // the threads that evaluate terms inside the span loops
   int* s = (int*)c.s; int* map = (int*)c.map; int* cum = (int*)c.cum; int* off = (int*)c.off;
   int* plist = (int*)c.plist; int* pcnt = (int*)c.pcnt;
   float* F = B.fws + sq.fws_off;
@@ -620,18 +633,35 @@ __global__ __launch_bounds__(CF_FOLD_THREADS) void k_contrafold(cf_batch B, int 
   for (int k = tid; k < CF_INTS(L); k += nt) B.iws[sq.iws_off + k] = s_ints[k];
 
 #define CF_STAMP(k) if (B.stamps && blockIdx.x == 0 && tid == 0) B.stamps[k] = wall_clock64()
+  if (B.stamps && blockIdx.x == 0 && tid == 0) B.stamps[5] = B.stamps[6] = 0;
   CF_STAMP(0);
   // ---- inside: span ascending
+  if (overlap) {  // the first span's terms (none: spans below 2 have no single-branch term, but the lists must exist)
+    cf_inside_terms(c, 0, FCi, 0, 0, nt);
+    __syncthreads();
+  }
   for (int d = 0; d <= L; ++d) {
-    const bool terms = c.has_pool && d >= 2;  // shorter spans have no single-branch term
-    if (terms) {
-      cf_inside_terms(c, d, FCi);
+    if (overlap) {
+      // cells of span d from buffer d & 1; meanwhile the other wavefronts evaluate span d + 1 (its terms read FC of spans
+      // d - 1 and below, and the ring slot span d overwrites held span d - 33) into the other buffer, whose bump counter
+      // was cleared during span d - 1
+      c.cur = d & 1;
+      if (tid == 0) c.ptop[d & 1] = 0;  // for span d + 2; nothing bumps or reads this counter now
+      if (tid >= tw0) {
+        if (d + 1 <= L) cf_inside_terms(c, d + 1, FCi, (d + 1) & 1, tw0, twn);
+      } else {
+        for (int i = cid; i + d <= L; i += cnt_) cf_inside_cell(c, i, i + d, FCi, FMi, FM1i);
+      }
       __syncthreads();
-    } else if (c.has_pool) {
-      for (int i = tid; i + d <= L; i += nt) c.tbase[i] = -1;
-      __syncthreads();
+      continue;
     }
-    if (tid == 0 && c.has_pool) *c.ptop = 0;  // every bump of this span is behind the barrier, the next span's in front of the one below
+    if (c.has_pool) {
+      const unsigned long long t0 = (B.stamps && blockIdx.x == 0 && tid == 0) ? wall_clock64() : 0;
+      cf_inside_terms(c, d, FCi, 0, 0, nt);
+      __syncthreads();
+      if (B.stamps && blockIdx.x == 0 && tid == 0) B.stamps[5] += wall_clock64() - t0;
+    }
+    if (tid == 0 && c.has_pool) c.ptop[0] = 0;  // every bump of this span is behind the barrier, the next span's in front of the one below
     for (int i = cid; i + d <= L; i += cnt_) cf_inside_cell(c, i, i + d, FCi, FMi, FM1i);
     __syncthreads();
   }
@@ -687,12 +717,31 @@ __global__ __launch_bounds__(CF_FOLD_THREADS) void k_contrafold(cf_batch B, int 
   }
   CF_STAMP(3);
   // main sweep: span descending
+  if (tid == 0 && c.has_pool) c.ptop[0] = c.ptop[1] = 0;
+  __syncthreads();
+  if (overlap) {
+    cf_outside_terms(c, L, FCo, L & 1, 0, nt);
+    __syncthreads();
+  }
   for (int d = L; d >= 0; --d) {
-    if (c.has_pool) {
-      cf_outside_terms(c, d, FCo);
+    if (overlap) {  // as in the inside pass: span d - 1's sources are FCo of spans d + 1 and above
+      c.cur = d & 1;
+      if (tid == 0) c.ptop[d & 1] = 0;
+      if (tid >= tw0) {
+        if (d - 1 >= 0) cf_outside_terms(c, d - 1, FCo, (d - 1) & 1, tw0, twn);
+      } else {
+        for (int a = cid; a + d <= L; a += cnt_) cf_outside_cell(c, a, a + d, FCi, FMi, FM1i, F5i, F5o, FCo, FMo, FM1o, FM2o);
+      }
       __syncthreads();
+      continue;
     }
-    if (tid == 0 && c.has_pool) *c.ptop = 0;
+    if (c.has_pool) {
+      const unsigned long long t0 = (B.stamps && blockIdx.x == 0 && tid == 0) ? wall_clock64() : 0;
+      cf_outside_terms(c, d, FCo, 0, 0, nt);
+      __syncthreads();
+      if (B.stamps && blockIdx.x == 0 && tid == 0) B.stamps[6] += wall_clock64() - t0;
+    }
+    if (tid == 0 && c.has_pool) c.ptop[0] = 0;
     for (int a = cid; a + d <= L; a += cnt_) cf_outside_cell(c, a, a + d, FCi, FMi, FM1i, F5i, F5o, FCo, FMo, FM1o, FM2o);
     __syncthreads();
   }
@@ -773,22 +822,32 @@ int contrafold_launch(const cf_batch& B, uint32_t nseq, uint32_t max_len, hipStr
   const size_t ring = (size_t)CF_RING * (max_len + 1) * sizeof(float);
   const size_t budget = 100 * 1024;  // dynamic LDS (static: score tables ~11 KB)
   if (ints > budget) return DAFS_HIP_ETOOLONG;
-  const int use_ring = ints + ring <= budget && !getenv("DAFS_HIP_CF_NORING");  // the env switch is a tuning aid
-  size_t lds = ints + (use_ring ? ring : 0);
-  // the term pool takes what is left of the CU's LDS behind the kernel's static tables (at least two full lists, or none)
-  int pool_floats = 0;
+  // What the CU's LDS is split into, behind the kernel's static tables: the integer side tables (always), the term pool and
+  // the ring of recent FC spans.  The pool comes first: it is what takes the term evaluation out of the chains; the
+  // ring only shortens the FC reads of that evaluation, which the whole workgroup issues in parallel anyway.  So the
+  // ring is kept when a pool of ~80 terms per row (the demand of a random sequence: 3/8 of the cells close a pair,
+  // ~150 terms each) still fits beside it, and dropped otherwise (from ~330 nt on).
   size_t stat = 28 * 1024;  // static LDS of k_contrafold (score tables, log-sum-exp tables)
   const size_t total = 160 * 1024 - 512;
   {
     hipFuncAttributes at;
     if (hipFuncGetAttributes(&at, (const void*)k_contrafold) == hipSuccess) stat = at.sharedSizeBytes;
     else (void)hipGetLastError();
-    const size_t fixed = lds + (2 * ((size_t)max_len + 1) + 1) * sizeof(int);
-    if (use_ring && !getenv("DAFS_HIP_CF_NOPOOL") && stat + fixed + 2 * 496 * sizeof(float) <= total) {
-      pool_floats = (int)((total - stat - fixed) / sizeof(float));
-      lds = fixed + (size_t)pool_floats * sizeof(float);
-    }
   }
+  const size_t pool_ints = (4 * ((size_t)max_len + 1) + 2) * sizeof(int);
+  const size_t pool_want = (size_t)80 * (max_len + 1) * sizeof(float);
+  const bool pool_on = !getenv("DAFS_HIP_CF_NOPOOL") && stat + ints + pool_ints + 2 * 496 * sizeof(float) <= total;
+  int use_ring = ints + ring <= budget && !getenv("DAFS_HIP_CF_NORING");  // the env switches are tuning aids
+  if (use_ring && pool_on && stat + ints + ring + pool_ints + pool_want > total) use_ring = 0;
+  size_t lds = ints + (use_ring ? ring : 0);
+  int pool_floats = 0;
+  if (pool_on) {
+    const size_t fixed = lds + pool_ints;
+    pool_floats = (int)((total - stat - fixed) / sizeof(float));
+    lds = fixed + (size_t)pool_floats * sizeof(float);
+  }
+  // two halves (terms of the next span evaluated beside the cells of this one) when each still holds the typical demand
+  int pool_bufs = (pool_floats / 2 >= (int)(pool_want / sizeof(float)) && !getenv("DAFS_HIP_CF_NOOVERLAP")) ? 2 : 1;
   int cell_waves = 8;
   if (const char* e = getenv("DAFS_HIP_CF_CELL_WAVES")) {  // tuning aid
     const int v = atoi(e);
@@ -803,7 +862,7 @@ int contrafold_launch(const cf_batch& B, uint32_t nseq, uint32_t max_len, hipStr
     const int v = atoi(e);
     if (v >= 64 && v <= CF_FOLD_THREADS && v % 64 == 0) fold_threads = v;
   }
-  hipLaunchKernelGGL(k_contrafold, dim3(nseq), dim3(fold_threads), lds, st, B, use_ring, pool_floats, cell_waves);
+  hipLaunchKernelGGL(k_contrafold, dim3(nseq), dim3(fold_threads), lds, st, B, use_ring, pool_floats, cell_waves, pool_bufs);
   if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
   hipLaunchKernelGGL(k_contrafold_posterior, dim3(max_len + 1, nseq), dim3(CF_THREADS), ints, st, B);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
