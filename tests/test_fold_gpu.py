@@ -68,6 +68,35 @@ def test_sequences_too_long_for_the_lds_ring(ctx, oracle, monkeypatch):
     assert post.tobytes() == t._orc_fold_post(oracle, s, cons).tobytes()
 
 
+def test_term_pool_forms(ctx, oracle, monkeypatch):
+    """The single-branch terms of a span are evaluated into an LDS pool before the cells fold them (k_contrafold).  Every
+    form must give the oracle's bits: lists that overflow the pool (a GC repeat pairs everywhere: ~250 terms for every
+    second cell, several times what the pool holds, so most cells walk their partners themselves), the pool without
+    the FC ring beside it (from ~330 nt on), one buffer instead of two, no pool at all, and other splits of the
+    wavefronts between cells and terms."""
+    import test_oracle_cpu as t
+    rng = np.random.default_rng(17)
+    dense = ["GC" * 90, "GU" * 70 + "ACGU" * 10, "G" * 60 + "C" * 60]
+    for s in dense:
+        post, _ = ctx.fold_posterior_dense(s)
+        assert post.tobytes() == t._orc_fold_post(oracle, s).tobytes(), s[:8]
+    s400 = "".join(rng.choice(list("ACGU"), 400))
+    post, _ = ctx.fold_posterior_dense(s400)
+    want400 = t._orc_fold_post(oracle, s400)
+    assert post.tobytes() == want400.tobytes()
+    fuzz = ["".join(rng.choice(list("ACGU" if k % 2 else "ACGUTN"), L)) for k, L in enumerate([2, 3, 9, 33, 64, 100, 181])] + [dense[0]]
+    want = [t._orc_fold_post(oracle, s) for s in fuzz]
+    for env in ({"DAFS_HIP_CF_NOPOOL": "1"}, {"DAFS_HIP_CF_NOOVERLAP": "1"}, {"DAFS_HIP_CF_CELL_WAVES": "16"},
+                {"DAFS_HIP_CF_CELL_WAVES": "3"}, {"DAFS_HIP_CF_THREADS": "256"}, {"DAFS_HIP_CF_NORING": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for s, w in zip(fuzz, want):
+            post, _ = ctx.fold_posterior_dense(s)
+            assert post.tobytes() == w.tobytes(), (env, len(s))
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_batch_rows_vs_oracle(ctx, oracle):
     seqs = [s for _, s in synth.random_set(5, 70, seed=21)] + ["ACGU", "GGGAAACCCTTNN"]
     ctx.set_sequences(seqs)
