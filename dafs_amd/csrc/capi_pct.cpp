@@ -92,8 +92,12 @@ static int consistency_parts(dafs_hip_ctx* c, float w_pct_a, float w_pct_s, int 
   if (!raw.valid || raw.n_tasks != all || (c->sim.empty() && !fourway)) return DAFS_HIP_EINVAL;
   if (fourway && !c->bp[0].valid) return DAFS_HIP_EINVAL;
   const uint32_t max_len = c->max_len();
-  const mp_store_dev mpv = raw.view(c->d_len.ptr, n);
+  mp_store_dev mpv = raw.view(c->d_len.ptr, n);
   int rc;
+  // the row kernels gather {column, value} pairs: one interleaved copy of the input entries per transform
+  if ((rc = c->mp_ent2.reserve(raw.pool_used + 1))) return rc;
+  if ((rc = pct_interleave_launch(raw.col.ptr, raw.val.ptr, c->mp_ent2.ptr, raw.pool_used, c->stream))) return rc;
+  mpv.ent2 = c->mp_ent2.ptr;
   if ((rc = c->counters.reserve(4))) return rc;
   if (pair_end == 0) pair_end = all;
   if (pair_begin > pair_end || pair_end > all) return DAFS_HIP_EINVAL;

@@ -42,13 +42,13 @@ namespace dafs {
 
 template <int Q>
 __device__ __forceinline__ uint32_t row_bcast(uint32_t v) {  // lane Q of every 16-lane row, to the whole row
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + Q, 0xF, 0xF, false);
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x150 + Q, 0xF, 0xF, false);  // every lane has a source: no `old` operand to set up
 }
 template <int Q>
 __device__ __forceinline__ float row_bcastf(float v) { return __uint_as_float(row_bcast<Q>(__float_as_uint(v))); }
 
 struct pct_item {  // one (z, k) of a row, held by one lane of the row's group
-  uint32_t ptr_lo, ptr_hi;  // first entry of mp[z][y][k] in the pool
+  uint32_t ptr_lo, ptr_hi;  // address of the first entry of mp[z][y][k] in the interleaved pool (a byte address: one 64-bit add per fetch)
   uint32_t n;               // its entries; an identity row (z == y) has n == 1 and ptr == ~0
   uint32_t j;               // the column of an identity row
   float pik, w;
@@ -57,48 +57,52 @@ struct pct_item {  // one (z, k) of a row, held by one lane of the row's group
 // Items Q..15 of a round: phase A fetches the first 16 entries of every item's b-row (all loads in flight
 // together), phase B applies the items in order.  Entries of one item have distinct columns, so the lanes
 // of a group update the row accumulator together; the groups of a wavefront are different rows.
+// which of the 16 item slots of a round hold, in some group of the wavefront, a b-row longer than a group (wave-uniform)
+__device__ __forceinline__ uint32_t pct_long_slots(uint32_t n) {
+  const unsigned long long m = __ballot(n > 16u);
+  return (uint32_t)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xFFFFull);
+}
+
 template <int Q>
 struct pct_round {
-  static __device__ __forceinline__ void fetch(const uint32_t* __restrict__ col, const float* __restrict__ val, const pct_item& it, int t, uint32_t (&jc)[16],
-                                               float (&pv)[16]) {
+  static __device__ __forceinline__ void fetch(const uint2* __restrict__ ent, const pct_item& it, int t, uint32_t (&jc)[16], float (&pv)[16]) {
     const uint32_t n = row_bcast<Q>(it.n), lo = row_bcast<Q>(it.ptr_lo), hi = row_bcast<Q>(it.ptr_hi), jid = row_bcast<Q>(it.j);
     const bool ident = (lo & hi) == 0xFFFFFFFFu;
-    jc[Q] = jid; pv[Q] = 1.0f;
-    if ((uint32_t)t < n && !ident) {
-      const uint64_t e = (((uint64_t)hi << 32) | lo) + (uint32_t)t;
-      jc[Q] = col[e]; pv[Q] = val[e];
-    }
-    pct_round<Q + 1>::fetch(col, val, it, t, jc, pv);
+    // column and value in one 8-byte load; the pair leaves the branch as loaded (taking it apart inside would make every
+    // load wait for itself) and is taken apart after the last one has been issued
+    uint2 cv = make_uint2(jid, 0x3F800000u);
+    if ((uint32_t)t < n && !ident) cv = ((const uint2*)(((uint64_t)hi << 32) | lo))[t];
+    pct_round<Q + 1>::fetch(ent, it, t, jc, pv);
+    jc[Q] = cv.x; pv[Q] = __uint_as_float(cv.y);
   }
   // jlo: only columns >= jlo take part (the base-pair transform keeps i < j)
-  static __device__ __forceinline__ void apply(const uint32_t* __restrict__ col, const float* __restrict__ val, const pct_item& it, int t, uint32_t jlo,
-                                               const uint32_t (&jc)[16], const float (&pv)[16], float* acc) {
+  static __device__ __forceinline__ void apply(const uint2* __restrict__ ent, const pct_item& it, int t, uint32_t jlo, const uint32_t (&jc)[16],
+                                               const float (&pv)[16], float* acc, uint32_t longq) {
     const uint32_t n = row_bcast<Q>(it.n);
     const float pik = row_bcastf<Q>(it.pik), w = row_bcastf<Q>(it.w);
     if ((uint32_t)t < n && jc[Q] >= jlo) acc[jc[Q]] += pik * pv[Q] * w;  // dafs.cpp:300 / :308 / :316, :359 / :368
-    if (__any(n > 16)) {  // a b-row longer than the group: the rest of it, before the next item
+    if (longq & (1u << Q)) {  // (scalar) a b-row longer than the group: the rest of it, before the next item
       const uint32_t lo = row_bcast<Q>(it.ptr_lo), hi = row_bcast<Q>(it.ptr_hi);
-      const uint64_t base = ((uint64_t)hi << 32) | lo;
+      const uint2* base = (const uint2*)(((uint64_t)hi << 32) | lo);
       uint32_t nmax = n;
 #pragma unroll
       for (int o = 16; o < 64; o <<= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, o));
       for (uint32_t e0 = 16; e0 < nmax; e0 += 16) {
         wave_lds_fence();
         if (e0 + (uint32_t)t < n) {
-          const uint64_t e = base + e0 + (uint32_t)t;
-          const uint32_t jj = col[e];
-          if (jj >= jlo) acc[jj] += pik * val[e] * w;
+          const uint2 cv = base[e0 + (uint32_t)t];
+          if (cv.x >= jlo) acc[cv.x] += pik * __uint_as_float(cv.y) * w;
         }
       }
     }
     wave_lds_fence();
-    pct_round<Q + 1>::apply(col, val, it, t, jlo, jc, pv, acc);
+    pct_round<Q + 1>::apply(ent, it, t, jlo, jc, pv, acc, longq);
   }
 };
 template <>
 struct pct_round<16> {
-  static __device__ __forceinline__ void fetch(const uint32_t*, const float*, const pct_item&, int, uint32_t (&)[16], float (&)[16]) {}
-  static __device__ __forceinline__ void apply(const uint32_t*, const float*, const pct_item&, int, uint32_t, const uint32_t (&)[16], const float (&)[16], float*) {}
+  static __device__ __forceinline__ void fetch(const uint2*, const pct_item&, int, uint32_t (&)[16], float (&)[16]) {}
+  static __device__ __forceinline__ void apply(const uint2*, const pct_item&, int, uint32_t, const uint32_t (&)[16], const float (&)[16], float*, uint32_t) {}
 };
 
 __global__ __launch_bounds__(256) void k_pct_rows(pct_match_args a, uint32_t pair0, uint32_t row_cap) {
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256) void k_pct_rows(pct_match_args a, uint32_t pai
         id = zid[zz];
         k = i;
         it.pik = 1.0f;
-        if (!(id & 0x80000000u)) { const uint64_t e = zaent[zz] + (tl - zoff[zz]); k = a.in.col[e]; it.pik = a.in.val[e]; }
+        if (!(id & 0x80000000u)) { const uint2 cv = a.in.ent2[zaent[zz] + (tl - zoff[zz])]; k = cv.x; it.pik = __uint_as_float(cv.y); }
       }
       if (have) {
         const uint32_t z = id & 0x3FFFFFFFu;
@@ -217,13 +221,14 @@ __global__ __launch_bounds__(256) void k_pct_rows(pct_match_args a, uint32_t pai
         else {
           const uint32_t bb = a.in.rowptr_pool[b_rp[z] + k], be = a.in.rowptr_pool[b_rp[z] + k + 1];
           const uint64_t ptr = b_ent[z] + bb;
-          it.n = be - bb; it.ptr_lo = (uint32_t)ptr; it.ptr_hi = (uint32_t)(ptr >> 32);
+          const uint64_t adr = (uint64_t)(a.in.ent2 + ptr);
+          it.n = be - bb; it.ptr_lo = (uint32_t)adr; it.ptr_hi = (uint32_t)(adr >> 32);
         }
       }
       uint32_t jc[16];
       float pv[16];
-      pct_round<0>::fetch(a.in.col, a.in.val, it, t, jc, pv);
-      pct_round<0>::apply(a.in.col, a.in.val, it, t, 0u, jc, pv, acc);
+      pct_round<0>::fetch(a.in.ent2, it, t, jc, pv);
+      pct_round<0>::apply(a.in.ent2, it, t, 0u, jc, pv, acc, pct_long_slots(it.n));
     }
     wave_lds_fence();
   }
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(256) void k_pct_bp_rows(pct_bp_args a, uint32_t row
         my_y = zid[zz];
         uint32_t k = i;
         my_pik = 1.0f;
-        if (my_y != x) { const uint64_t e = zaent[zz] + (tl - zoff[zz]); k = a.mp.col[e]; my_pik = a.mp.val[e]; }
+        if (my_y != x) { const uint2 cv = a.mp.ent2[zaent[zz] + (tl - zoff[zz])]; k = cv.x; my_pik = __uint_as_float(cv.y); }
         const row_ref b = bp_row(a.bp, my_y, k);  // (l, p_kl)
         my_nb = b.n;
         const uint64_t off = (uint64_t)(b.col - a.bp.col);
@@ -446,13 +451,14 @@ __global__ __launch_bounds__(256) void k_pct_bp_rows(pct_bp_args a, uint32_t row
             else {
               const uint32_t cb = a.mp.rowptr_pool[c_rp[yq] + l], ce = a.mp.rowptr_pool[c_rp[yq] + l + 1];
               const uint64_t ptr = c_ent[yq] + cb;
-              it.n = ce - cb; it.ptr_lo = (uint32_t)ptr; it.ptr_hi = (uint32_t)(ptr >> 32);
+              const uint64_t adr = (uint64_t)(a.mp.ent2 + ptr);
+              it.n = ce - cb; it.ptr_lo = (uint32_t)adr; it.ptr_hi = (uint32_t)(adr >> 32);
             }
           }
           uint32_t jc[16];
           float pv[16];
-          pct_round<0>::fetch(a.mp.col, a.mp.val, it, t, jc, pv);
-          pct_round<0>::apply(a.mp.col, a.mp.val, it, t, i + 1, jc, pv, acc);
+          pct_round<0>::fetch(a.mp.ent2, it, t, jc, pv);
+          pct_round<0>::apply(a.mp.ent2, it, t, i + 1, jc, pv, acc, pct_long_slots(it.n));
         }
       }
     }
@@ -654,6 +660,18 @@ __global__ __launch_bounds__(256) void k_fourway_rows(pct_match_args a, uint32_t
     }
     tile[(size_t)ra * L2 + cb] = post;
   }
+}
+
+__global__ __launch_bounds__(256) void k_mp_interleave(const uint32_t* __restrict__ col, const float* __restrict__ val, uint2* __restrict__ ent2, uint64_t n) {
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x)
+    ent2[e] = make_uint2(col[e], __float_as_uint(val[e]));
+}
+
+int pct_interleave_launch(const uint32_t* col, const float* val, uint2* ent2, uint64_t n, hipStream_t st) {
+  if (!n) return DAFS_HIP_OK;
+  const uint64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_mp_interleave, dim3((uint32_t)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, col, val, ent2, n);
+  return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 
 int pct_fourway_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint32_t count, hipStream_t st) {

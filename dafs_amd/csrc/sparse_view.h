@@ -14,6 +14,8 @@ struct mp_store_dev {
   const uint32_t* rowptr_pool;
   const uint32_t* col;
   const float* val;
+  const uint2* ent2;             // optional: the same entries interleaved, {col, bits of val} (the consistency kernels' gathers
+                                 // fetch one line per row instead of two; built per transform by pct_interleave_launch)
   const uint64_t* pair_off;      // per task: first entry of mp[a][b]; mp[b][a] follows after nnz entries
   const uint32_t* pair_nnz;      // per task
   const uint64_t* rp_off;        // per task: first row pointer (len[a]+1 of them, then len[b]+1)
