@@ -98,6 +98,9 @@ static int consistency_parts(dafs_hip_ctx* c, float w_pct_a, float w_pct_s, int 
   if ((rc = c->mp_ent2.reserve(raw.pool_used + 1))) return rc;
   if ((rc = pct_interleave_launch(raw.col.ptr, raw.val.ptr, c->mp_ent2.ptr, raw.pool_used, c->stream))) return rc;
   mpv.ent2 = c->mp_ent2.ptr;
+  if ((rc = c->mp_ident2.reserve(max_len + 1))) return rc;
+  if ((rc = pct_ident_launch(c->mp_ident2.ptr, max_len + 1, c->stream))) return rc;
+  mpv.ident2 = c->mp_ident2.ptr;
   if ((rc = c->counters.reserve(4))) return rc;
   if (pair_end == 0) pair_end = all;
   if (pair_begin > pair_end || pair_end > all) return DAFS_HIP_EINVAL;

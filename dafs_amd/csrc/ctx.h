@@ -60,7 +60,7 @@ struct mp_store {
   dev_buf<uint64_t> pair_off, rp_off;
   mp_store_dev view(const uint32_t* d_len, uint32_t nseq) const {
     mp_store_dev v;
-    v.rowptr_pool = rowptr_pool.ptr; v.col = col.ptr; v.val = val.ptr; v.ent2 = nullptr; v.pair_off = pair_off.ptr;
+    v.rowptr_pool = rowptr_pool.ptr; v.col = col.ptr; v.val = val.ptr; v.ent2 = nullptr; v.ident2 = nullptr; v.pair_off = pair_off.ptr;
     v.pair_nnz = pair_nnz.ptr; v.rp_off = rp_off.ptr; v.task_of_pair = d_task_of_pair.ptr; v.len = d_len; v.nseq = nseq;
     return v;
   }
@@ -117,6 +117,7 @@ struct dafs_hip_ctx {
   std::vector<float> sim;
   dafs::dev_buf<float> d_sim;
   dafs::dev_buf<uint32_t> d_pair_x, d_pair_y;
+  dafs::dev_buf<uint2> mp_ident2;  // rows of an identity matrix, {k, 1.0f}
   dafs::dev_buf<uint2> mp_ent2;  // interleaved copy of the un-relaxed matching store's entries (consistency transforms)
   // CONTRAfold workspaces
   bool cf_params_ready = false;
@@ -216,7 +217,7 @@ struct dafs_hip_ctx {
 
   void free_all() {
     codes.release(); d_len.release(); d_seq_rp_off.release(); tasks.release(); scratch.release(); task_sim.release();
-    counters.release(); d_sim.release(); d_pair_x.release(); d_pair_y.release(); mp_ent2.release(); work.release(); work2.release(); d_nodes.release(); d_paused.release(); d_nodes2.release(); d_paused2.release(); d_tref.release(); for (int k = 0; k < 2; ++k) { d_pack_off[k].release(); d_pack[k].release(); } dd_release();
+    counters.release(); d_sim.release(); d_pair_x.release(); d_pair_y.release(); mp_ent2.release(); mp_ident2.release(); work.release(); work2.release(); d_nodes.release(); d_paused.release(); d_nodes2.release(); d_paused2.release(); d_tref.release(); for (int k = 0; k < 2; ++k) { d_pack_off[k].release(); d_pack[k].release(); } dd_release();
     for (int k = 0; k < 2; ++k) { if (h_paused[k]) (void)hipHostFree(h_paused[k]); h_paused[k] = nullptr; h_paused_cap[k] = 0; }
     d_cf_params.release(); cf_seqs.release(); cf_codes.release(); cf_iws.release(); cf_cons.release(); cf_fws.release(); cf_post.release(); cf_logz.release();
     for (int k = 0; k < 2; ++k) { mp[k].release(); bp[k].release(); }

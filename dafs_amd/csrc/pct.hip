@@ -47,10 +47,10 @@ __device__ __forceinline__ uint32_t row_bcast(uint32_t v) {  // lane Q of every 
 template <int Q>
 __device__ __forceinline__ float row_bcastf(float v) { return __uint_as_float(row_bcast<Q>(__float_as_uint(v))); }
 
+typedef __attribute__((address_space(1))) const uint2 pct_gent;  // entries are in global memory: global_load, not flat_load
 struct pct_item {  // one (z, k) of a row, held by one lane of the row's group
   uint32_t ptr_lo, ptr_hi;  // address of the first entry of mp[z][y][k] in the interleaved pool (a byte address: one 64-bit add per fetch)
-  uint32_t n;               // its entries; an identity row (z == y) has n == 1 and ptr == ~0
-  uint32_t j;               // the column of an identity row
+  uint32_t n;               // its entries; an identity row (z == y) is the one entry {k, 1} of ident2
   float pik, w;
 };
 
@@ -66,12 +66,11 @@ __device__ __forceinline__ uint32_t pct_long_slots(uint32_t n) {
 template <int Q>
 struct pct_round {
   static __device__ __forceinline__ void fetch(const uint2* __restrict__ ent, const pct_item& it, int t, uint32_t (&jc)[16], float (&pv)[16]) {
-    const uint32_t n = row_bcast<Q>(it.n), lo = row_bcast<Q>(it.ptr_lo), hi = row_bcast<Q>(it.ptr_hi), jid = row_bcast<Q>(it.j);
-    const bool ident = (lo & hi) == 0xFFFFFFFFu;
+    const uint32_t n = row_bcast<Q>(it.n), lo = row_bcast<Q>(it.ptr_lo), hi = row_bcast<Q>(it.ptr_hi);
     // column and value in one 8-byte load; the pair leaves the branch as loaded (taking it apart inside would make every
     // load wait for itself) and is taken apart after the last one has been issued
-    uint2 cv = make_uint2(jid, 0x3F800000u);
-    if ((uint32_t)t < n && !ident) cv = ((const uint2*)(((uint64_t)hi << 32) | lo))[t];
+    uint2 cv = make_uint2(lo, hi);  // lanes without an entry keep what is in the registers anyway (never used: apply tests t < n)
+    if ((uint32_t)t < n) cv = ((const pct_gent*)(((uint64_t)hi << 32) | lo))[t];
     pct_round<Q + 1>::fetch(ent, it, t, jc, pv);
     jc[Q] = cv.x; pv[Q] = __uint_as_float(cv.y);
   }
@@ -83,7 +82,7 @@ struct pct_round {
     if ((uint32_t)t < n && jc[Q] >= jlo) acc[jc[Q]] += pik * pv[Q] * w;  // dafs.cpp:300 / :308 / :316, :359 / :368
     if (longq & (1u << Q)) {  // (scalar) a b-row longer than the group: the rest of it, before the next item
       const uint32_t lo = row_bcast<Q>(it.ptr_lo), hi = row_bcast<Q>(it.ptr_hi);
-      const uint2* base = (const uint2*)(((uint64_t)hi << 32) | lo);
+      const pct_gent* base = (const pct_gent*)(((uint64_t)hi << 32) | lo);
       uint32_t nmax = n;
 #pragma unroll
       for (int o = 16; o < 64; o <<= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, o));
@@ -201,7 +200,7 @@ __global__ __launch_bounds__(256) void k_pct_rows(pct_match_args a, uint32_t pai
     for (uint32_t w0 = 0; w0 < T1max; w0 += PCT_G) {
       const uint32_t tl = w0 + (uint32_t)t;
       pct_item it;
-      it.ptr_lo = 0; it.ptr_hi = 0; it.n = 0; it.j = 0; it.pik = 0.0f; it.w = 0.0f;
+      it.ptr_lo = 0; it.ptr_hi = 0; it.n = 0; it.pik = 0.0f; it.w = 0.0f;
       uint32_t k = 0, id = 0;
       const bool have = tl < T1;
       if (have) {
@@ -216,9 +215,10 @@ __global__ __launch_bounds__(256) void k_pct_rows(pct_match_args a, uint32_t pai
       if (have) {
         const uint32_t z = id & 0x3FFFFFFFu;
         it.w = wz[z];
-        it.j = k;
-        if (id & 0x40000000u) { it.n = 1; it.ptr_lo = 0xFFFFFFFFu; it.ptr_hi = 0xFFFFFFFFu; }
-        else {
+        if (id & 0x40000000u) {
+          const uint64_t adr = (uint64_t)(a.in.ident2 + k);
+          it.n = 1; it.ptr_lo = (uint32_t)adr; it.ptr_hi = (uint32_t)(adr >> 32);
+        } else {
           const uint32_t bb = a.in.rowptr_pool[b_rp[z] + k], be = a.in.rowptr_pool[b_rp[z] + k + 1];
           const uint64_t ptr = b_ent[z] + bb;
           const uint64_t adr = (uint64_t)(a.in.ent2 + ptr);
@@ -440,15 +440,16 @@ __global__ __launch_bounds__(256) void k_pct_bp_rows(pct_bp_args a, uint32_t row
         const uint64_t boff = ((uint64_t)(uint32_t)__shfl((int)my_hi, q, PCT_G) << 32) | (uint32_t)__shfl((int)my_lo, q, PCT_G);
         for (uint32_t e0 = 0; e0 < nbmax; e0 += PCT_G) {
           pct_item it;
-          it.ptr_lo = 0; it.ptr_hi = 0; it.n = 0; it.j = 0; it.pik = 0.0f; it.w = 0.0f;
+          it.ptr_lo = 0; it.ptr_hi = 0; it.n = 0; it.pik = 0.0f; it.w = 0.0f;
           if (e0 + (uint32_t)t < nb) {
             const uint32_t l = a.bp.col[boff + e0 + (uint32_t)t];
             const float pkl = a.bp.val[boff + e0 + (uint32_t)t];
             it.pik = pkl * pik;  // p_kl * p_ik, then * p_jl * w (:359, :368)
             it.w = wy[yq];
-            it.j = l;
-            if (yq == x) { it.n = 1; it.ptr_lo = 0xFFFFFFFFu; it.ptr_hi = 0xFFFFFFFFu; }  // mp[x][x][l] = {(l, 1)}
-            else {
+            if (yq == x) {  // mp[x][x][l] = {(l, 1)}
+              const uint64_t adr = (uint64_t)(a.mp.ident2 + l);
+              it.n = 1; it.ptr_lo = (uint32_t)adr; it.ptr_hi = (uint32_t)(adr >> 32);
+            } else {
               const uint32_t cb = a.mp.rowptr_pool[c_rp[yq] + l], ce = a.mp.rowptr_pool[c_rp[yq] + l + 1];
               const uint64_t ptr = c_ent[yq] + cb;
               const uint64_t adr = (uint64_t)(a.mp.ent2 + ptr);
@@ -665,6 +666,16 @@ __global__ __launch_bounds__(256) void k_fourway_rows(pct_match_args a, uint32_t
 __global__ __launch_bounds__(256) void k_mp_interleave(const uint32_t* __restrict__ col, const float* __restrict__ val, uint2* __restrict__ ent2, uint64_t n) {
   for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x)
     ent2[e] = make_uint2(col[e], __float_as_uint(val[e]));
+}
+
+__global__ __launch_bounds__(256) void k_mp_ident(uint2* __restrict__ ident2, uint32_t n) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) ident2[k] = make_uint2(k, 0x3F800000u);
+}
+int pct_ident_launch(uint2* ident2, uint32_t n, hipStream_t st) {
+  if (!n) return DAFS_HIP_OK;
+  hipLaunchKernelGGL(k_mp_ident, dim3((n + 255) / 256), dim3(256), 0, st, ident2, n);
+  return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 
 int pct_interleave_launch(const uint32_t* col, const float* val, uint2* ent2, uint64_t n, hipStream_t st) {
