@@ -47,7 +47,8 @@ __device__ __forceinline__ uint32_t row_bcast(uint32_t v) {  // lane Q of every 
 template <int Q>
 __device__ __forceinline__ float row_bcastf(float v) { return __uint_as_float(row_bcast<Q>(__float_as_uint(v))); }
 
-typedef __attribute__((address_space(1))) const uint2 pct_gent;  // entries are in global memory: global_load, not flat_load
+typedef uint32_t pct_u2 __attribute__((ext_vector_type(2)));  // (a builtin vector: HIP's uint2 class cannot be read through an address-space pointer)
+typedef __attribute__((address_space(1))) const pct_u2 pct_gent;  // entries are in global memory: global_load, not flat_load
 struct pct_item {  // one (z, k) of a row, held by one lane of the row's group
   uint32_t ptr_lo, ptr_hi;  // address of the first entry of mp[z][y][k] in the interleaved pool (a byte address: one 64-bit add per fetch)
   uint32_t n;               // its entries; an identity row (z == y) is the one entry {k, 1} of ident2
@@ -69,7 +70,7 @@ struct pct_round {
     const uint32_t n = row_bcast<Q>(it.n), lo = row_bcast<Q>(it.ptr_lo), hi = row_bcast<Q>(it.ptr_hi);
     // column and value in one 8-byte load; the pair leaves the branch as loaded (taking it apart inside would make every
     // load wait for itself) and is taken apart after the last one has been issued
-    uint2 cv = make_uint2(lo, hi);  // lanes without an entry keep what is in the registers anyway (never used: apply tests t < n)
+    pct_u2 cv = {lo, hi};  // lanes without an entry keep what is in the registers anyway (never used: apply tests t < n)
     if ((uint32_t)t < n) cv = ((const pct_gent*)(((uint64_t)hi << 32) | lo))[t];
     pct_round<Q + 1>::fetch(ent, it, t, jc, pv);
     jc[Q] = cv.x; pv[Q] = __uint_as_float(cv.y);
@@ -89,7 +90,7 @@ struct pct_round {
       for (uint32_t e0 = 16; e0 < nmax; e0 += 16) {
         wave_lds_fence();
         if (e0 + (uint32_t)t < n) {
-          const uint2 cv = base[e0 + (uint32_t)t];
+          const pct_u2 cv = base[e0 + (uint32_t)t];
           if (cv.x >= jlo) acc[cv.x] += pik * __uint_as_float(cv.y) * w;
         }
       }
