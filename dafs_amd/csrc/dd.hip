@@ -1341,13 +1341,32 @@ __device__ __forceinline__ uint32_t row_of_entry(const uint32_t* ptr, uint32_t R
   return lo;
 }
 
-__global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes, dd_params prm, uint32_t* ncbp_out, uint32_t pxptr_lds) {
+// parts == 1: one workgroup does everything.  parts == 4 (launches of a few nodes, where the node's set-up stands between
+// its children and its own first iteration): the lists of p_x, p_y, p_z and the alignment envelope + table initialisation
+// are four workgroups (blockIdx.y); each raises the node's arrival counter (sync[5], zero since the node was carved) when
+// its part is in memory, and the one that arrives last counts the consensus base pairs, which need all three lists.
+__global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes, dd_params prm, uint32_t* ncbp_out, uint32_t pxptr_lds, uint32_t parts) {
   const dd_node nd = nodes[blockIdx.x];
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const uint32_t L1 = nd.L1, L2 = nd.L2;
-  row_lists(L1, L1, nd.p_x, true, nd.px_ptr, nd.px_j, nd.xmap);
-  row_lists(L2, L2, nd.p_y, true, nd.py_ptr, nd.py_l, nd.ymap);
-  row_lists(L1, L2, nd.p_z, false, nd.pz_ptr, nd.pz_k, nullptr);
+  const uint32_t part = blockIdx.y;
+  if (parts == 1 || part == 0) row_lists(L1, L1, nd.p_x, true, nd.px_ptr, nd.px_j, nd.xmap);
+  if (parts == 1 || part == 1) row_lists(L2, L2, nd.p_y, true, nd.py_ptr, nd.py_l, nd.ymap);
+  if (parts == 1 || part == 2) row_lists(L1, L2, nd.p_z, false, nd.pz_ptr, nd.pz_k, nullptr);
+  if (parts > 1) {
+    if (part == 3) {  // alignment envelope + table initialisation
+      nw_envelope(L1, L2, nd.p_z, prm.th_a, nd.env, nd.x, nd.z);  // x / z double as scratch here
+      nw_init(L1, L2, nd.dp_z, nd.tr_z);
+    }
+    __shared__ uint32_t s_ticket;
+    __threadfence();  // this part's lists, before the arrival
+    __syncthreads();
+    if (tid == 0) s_ticket = atomicAdd(&nd.sync[5], 1u);
+    __syncthreads();
+    if (s_ticket != parts - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other parts' lists, after the arrival
+    if (tid == 0) nd.sync[5] = 0;
+  }
   // consensus base pairs per p_x entry (dafs.cpp:1022-1044)
   __shared__ uint32_t s_total;
   if (tid == 0) s_total = 0;
@@ -1382,9 +1401,10 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes,
     }
   }
   atomicAdd(&s_total, mine);
-  // alignment envelope + table initialisation
-  nw_envelope(L1, L2, nd.p_z, prm.th_a, nd.env, nd.x, nd.z);  // x / z double as scratch here
-  nw_init(L1, L2, nd.dp_z, nd.tr_z);
+  if (parts == 1) {  // alignment envelope + table initialisation
+    nw_envelope(L1, L2, nd.p_z, prm.th_a, nd.env, nd.x, nd.z);  // x / z double as scratch here
+    nw_init(L1, L2, nd.dp_z, nd.tr_z);
+  }
   __syncthreads();
   if (tid == 0 && ncbp_out) ncbp_out[blockIdx.x] = s_total;  // the host sizes the constraint block from this (one copy per call)
   if (tid == 0) { nd.info[0] = s_total; nd.info[1] = 0; nd.info[2] = 0; nd.info[3] = 0; nd.info[4] = 0; nd.info[5] = 0; nd.info[6] = 0; nd.info[7] = 0; }
@@ -2043,7 +2063,9 @@ int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, 
   if (lds > budget) lds = budget;  // longer row pointer arrays are searched in HBM
   int rc = lds_optin((const void*)k_node_lists, 1, lds, budget);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_node_lists, dim3(nnodes), dim3(DD_THREADS), lds, st, d_nodes, prm, d_ncbp, (uint32_t)lds);
+  // four workgroups per node when the launch is small (the nodes of the tree's critical chain are opened one or two at a time)
+  const uint32_t parts = (nnodes <= 16 && !getenv("DAFS_HIP_DD_LISTS1")) ? 4u : 1u;  // the env switch is a tuning aid
+  hipLaunchKernelGGL(k_node_lists, dim3(nnodes, parts), dim3(DD_THREADS), lds, st, d_nodes, prm, d_ncbp, (uint32_t)lds, parts);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, dd_params prm, hipStream_t st) {
