@@ -23,3 +23,19 @@ while i >= n:
     chain.append((i, res.dd_log[i][0]))
     i = left[i] if fin[left[i]] >= fin[right[i]] else right[i]
 print("chain (node, iterations):", chain)
+# slack of every node with many iterations: how much later its sibling's side finishes
+par = {}
+for i in range(n, 2 * n - 1):
+    par[left[i]] = i; par[right[i]] = i
+for i in range(n, 2 * n - 1):
+    if res.dd_log[i][0] >= 100:
+        # walk up: slack = min over ancestors of (finish of the other child - finish of this side)
+        j, slack = i, None
+        while j in par:
+            pj = par[j]
+            other = right[pj] if left[pj] == j else left[pj]
+            d = fin[other] - fin[j]
+            slack = d if slack is None else max(slack, d)
+            if d > 0: break
+            j = pj
+        print("node %d iters %d: finishes at %.1f ms; first ancestor where the other side is later: +%.1f ms" % (i, res.dd_log[i][0], fin[i] / 1e3, (slack or 0) / 1e3))
