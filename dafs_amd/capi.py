@@ -134,6 +134,7 @@ _nodes_round = _sig("dafs_hip_nodes_round", C.c_int, [C.c_void_p, C.c_uint32, C.
 _nodes_result = _sig("dafs_hip_nodes_result", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(NodeOutput)])
 _nodes_close = _sig("dafs_hip_nodes_close", C.c_int, [C.c_void_p])
 _nodes_memory = _sig("dafs_hip_nodes_memory", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
+_nodes_demotions = _sig("dafs_hip_nodes_demotions", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)])
 _update_basepairing = _sig("dafs_hip_update_basepairing", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
 _consensus_structure = _sig("dafs_hip_consensus_structure", C.c_int,
                             [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
@@ -447,6 +448,12 @@ class Context:
         r, u, p = C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(_nodes_memory(self._h, C.byref(r), C.byref(u), C.byref(p)))
         return r.value, u.value, p.value
+
+    def nodes_demotions(self):
+        """split-mode nodes that lost their folding workgroups and went on in the one-workgroup form (since nodes_close)"""
+        n = C.c_uint32()
+        check(_nodes_demotions(self._h, C.byref(n)))
+        return n.value
 
     def update_basepairing(self, seq, mask, ss):
         """DAFS::update_basepairing_probability (--bp-update): the L x L matrix re-estimated under the structure ss"""

@@ -13,8 +13,14 @@
 #include "../../include/dafs_hip.h"
 #include "ctx.h"
 #include "hip_util.h"
+#include "stage.h"
 
 namespace dafs {
+
+stage_recorder*& stage_current() {
+  static stage_recorder* cur = nullptr;
+  return cur;
+}
 
 static thread_local std::string g_last_error;
 bool hip_check(hipError_t e) {
@@ -138,9 +144,47 @@ extern "C" int dafs_hip_create(int device, dafs_hip_ctx** out) {
   return DAFS_HIP_OK;
 }
 
+// ---- per-kernel device timings (bench.py "stages"; stage.h) ----
+extern "C" int dafs_hip_stage_timing(dafs_hip_ctx* c, int enable) {
+  if (!c) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  if (hip_check(hipDeviceSynchronize())) return DAFS_HIP_ELAUNCH;
+  c->stages.clear();
+  if (enable) stage_current() = &c->stages;
+  else if (stage_current() == &c->stages) stage_current() = nullptr;
+  return DAFS_HIP_OK;
+}
+
+extern "C" int dafs_hip_stage_report(dafs_hip_ctx* c, dafs_stage_time* out, uint32_t cap, uint32_t* n) {
+  if (!c || !n || (cap && !out)) return DAFS_HIP_EINVAL;
+  if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
+  if (hip_check(hipDeviceSynchronize())) return DAFS_HIP_ELAUNCH;
+  double ms[ST_COUNT] = {0};
+  double longest[ST_COUNT] = {0};
+  uint32_t cnt[ST_COUNT] = {0};
+  for (const stage_recorder::rec& r : c->stages.recs) {
+    float t = 0.0f;
+    if (hip_check(hipEventElapsedTime(&t, r.a, r.b))) return DAFS_HIP_ELAUNCH;
+    ms[r.id] += t;
+    if (t > longest[r.id]) longest[r.id] = t;
+    ++cnt[r.id];
+  }
+  uint32_t k = 0;
+  for (int id = 0; id < ST_COUNT; ++id) {
+    if (!cnt[id]) continue;
+    if (k < cap) { out[k].kernel = kStageNames[id]; out[k].ms = ms[id]; out[k].longest_ms = longest[id]; out[k].launches = cnt[id]; }
+    ++k;
+  }
+  *n = k;
+  c->stages.clear();  // the next report starts from here
+  return DAFS_HIP_OK;
+}
+
 extern "C" void dafs_hip_destroy(dafs_hip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (stage_current() == &c->stages) stage_current() = nullptr;
+  c->stages.release();
   c->free_all();
   (void)hipStreamDestroy(c->fold_stream);
   (void)hipStreamDestroy(c->node_stream);

@@ -220,7 +220,62 @@ dd_params device_params(const dafs_dd_params* prm) {
 struct dd_lane { hipStream_t st; dev_buf<dd_node>* d_nodes; dev_buf<uint32_t>* d_paused; int id; };
 dd_lane lane_of(dafs_hip_ctx* c, int k) { return k == 0 ? dd_lane{c->stream, &c->d_nodes, &c->d_paused, 0} : dd_lane{c->node_stream, &c->d_nodes2, &c->d_paused2, 1}; }
 
-int nodes_open(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const dafs_node_input* in, const dd_params& dp) {
+// What a node's launch would read, checked on the host before anything is enqueued.  Every form of the folding DPs
+// reads one of the two score copies (s_x / s_y in sweep order for the column-owning register forms, s_xs / s_ys by span
+// for the span form), and nodes_open leaves out the copies no form of the node can use.  A plan that selects a form
+// whose copy is absent would make the kernel use a null base + cell offset as an address: that was the memory-access
+// fault of round 2 ("the fault at 16 x ~1100 columns": the multiplier updates wrote s_x[skew(i, j)] of
+// nodes beyond 1024 columns, whose s_x had just become optional).  The kernel's writes are guarded now; this check
+// turns any future mismatch between the carving and the form selection into DAFS_HIP_ELAUNCH instead of a fault.
+int plan_check(const dd_node& nd, bool split) {
+  auto bad = [](const char* what) {
+    fprintf(stderr, "dafs_hip: node plan refused: %s\n", what);
+    return DAFS_HIP_ELAUNCH;
+  };
+  const void* always[] = {nd.seq1, nd.seq2, nd.rank1, nd.rank2, nd.idx1, nd.idx2, nd.idxoff1, nd.idxoff2, nd.p_x, nd.p_y, nd.p_z, nd.q_x, nd.q_y, nd.q_z,
+                          nd.wx.dp, nd.wx.tr, nd.wx.ck, nd.wx.cv, nd.wx.cc, nd.wy.dp, nd.wy.tr, nd.wy.ck, nd.wy.cv, nd.wy.cc, nd.dp_z, nd.tr_z,
+                          nd.trb_x, nd.trb_y, nd.trk_x, nd.trk_y, nd.pz_s, nd.qz_s, nd.env, nd.env4, nd.xmap, nd.ymap, nd.zmap, nd.px_ptr, nd.px_j,
+                          nd.py_ptr, nd.py_l, nd.pz_ptr, nd.pz_k, nd.cz_ptr, nd.cz_k, nd.cx_flag, nd.cy_flag, nd.cz_flag, nd.cbp_cnt, nd.cbp, nd.sw,
+                          nd.tx, nd.ty, nd.tz, nd.x, nd.y, nd.z, nd.score, nd.info, nd.fstate, nd.sync};
+  for (const void* q : always)
+    if (!q) return bad("a null array in the node descriptor");
+  if (!nd.L1 || !nd.L2 || !nd.n1 || !nd.n2) return bad("empty child alignment");
+  const bool regx = dd_fold_cols(nd.L1) <= DD_WFOLD, regy = dd_fold_cols(nd.L2) <= DD_WFOLD;
+  if (!split) {
+    const uint32_t f = nd.lds_flags;
+    if ((f & 64u) && (!nd.s_xs || !nd.s_ys)) return bad("span form without the by-span score copies");
+    if ((f & 64u) && (nd.L1 > DD_SPAN_LMAX || nd.L2 > DD_SPAN_LMAX)) return bad("span form beyond its width");
+    if (!(f & 64u) && (f & (2u | 8u)) && regx && !nd.s_x) return bad("register form of the x folding without its sweep-order scores");
+    if (!(f & 64u) && (f & (4u | 8u)) && regy && !nd.s_y) return bad("register form of the y folding without its sweep-order scores");
+  } else {
+    if (nd.lds_flags & ~(1u | 32u)) return bad("a split leader keeps the alignment DP only");
+    for (int r = 0; r < 2; ++r) {
+      const uint32_t L = r ? nd.L2 : nd.L1;
+      const bool reg = r ? regy : regx;
+      const float* sweep = r ? nd.s_y : nd.s_x;
+      const float* byspan = r ? nd.s_ys : nd.s_xs;
+      if (nd.fold_fast & (16u << r)) {
+        if (!byspan) return bad("span-form folder without the by-span score copy");
+        if (L > DD_SPAN_LMAX) return bad("span-form folder beyond its width");
+      } else if ((nd.fold_fast & (5u << r)) && reg && !sweep) return bad("register-form folder without its sweep-order scores");
+    }
+  }
+  return DAFS_HIP_OK;
+}
+
+struct open_blocks {  // device blocks of the nodes an open call has carved so far (given back when the call fails)
+  std::vector<uint8_t*> blk0, blk1;
+  std::vector<size_t> bytes0, bytes1;
+};
+
+// DAFS_HIP_DD_FAIL_OPEN=k (tests): nodes_open fails with DAFS_HIP_ELAUNCH at its k-th stage (1 after the blocks and their
+// fills are queued, 2 after the lists, 3 after the second blocks, 4 after everything) -- the late-failure path
+bool fail_injected(int stage) {
+  const char* e = getenv("DAFS_HIP_DD_FAIL_OPEN");
+  return e && atoi(e) == stage;
+}
+
+int nodes_open_impl(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const dafs_node_input* in, const dd_params& dp, open_blocks& ob) {
   const mp_store& mps = c->mp[c->cur_mp];
   const bp_store& bps = c->bp[c->cur_bp];
   const uint32_t nseq = (uint32_t)c->len.size();
@@ -245,12 +300,10 @@ int nodes_open(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const dafs_n
   std::vector<dd_node> nodes(nnodes);
   std::vector<std::vector<uint8_t>> heads(nnodes);  // upload staging, alive until the first synchronisation below
   std::vector<size_t> lds(nnodes, 0), split_lds(nnodes, 0);
-  std::vector<uint8_t*> blk0(nnodes, nullptr), blk1(nnodes, nullptr);
-  std::vector<size_t> blk0_bytes(nnodes, 0), blk1_bytes(nnodes, 0);
-  auto undo = [&](int rc) {  // a failed open gives its blocks back
-    for (uint32_t b = 0; b < nnodes; ++b) { c->dd_free(blk0[b], blk0_bytes[b]); c->dd_free(blk1[b], blk1_bytes[b]); }
-    return rc;
-  };
+  ob.blk0.assign(nnodes, nullptr); ob.blk1.assign(nnodes, nullptr);
+  ob.bytes0.assign(nnodes, 0); ob.bytes1.assign(nnodes, 0);
+  std::vector<uint8_t*>&blk0 = ob.blk0, &blk1 = ob.blk1;
+  std::vector<size_t>&blk0_bytes = ob.bytes0, &blk1_bytes = ob.bytes1;
   for (uint32_t b = 0; b < nnodes; ++b) {
     const dafs_node_input& ni = in[b];
     dd_node& nd = nodes[b];
@@ -291,7 +344,7 @@ int nodes_open(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const dafs_n
         size_t base_z = (size_t)3 * ((L2 + 64) / 64) * 64 * 4;
         uint32_t lean = 0;
         if (base_z > kDdLdsBudget - 4096 || force_wide) { base_z /= 3; lean = 32u; }
-        if (base_z > kDdLdsBudget - 4096) return undo(DAFS_HIP_ETOOLONG);  // second alignment beyond ~38 000 columns
+        if (base_z > kDdLdsBudget - 4096) return DAFS_HIP_ETOOLONG;  // second alignment beyond ~38 000 columns
         auto nib = [](uint32_t L) { return ((size_t)L * (L + 1) / 2 + 7) / 8; };           // packed traceback codes, words
         // a fast folding DP: codes, the rows in flight (one per active lane), DD_CAP split rows per column
         auto fast = [&](uint32_t L) { return (nib(L) + dd_ring_words(L) + (size_t)DD_CAP * L) * 4; };
@@ -361,7 +414,7 @@ int nodes_open(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const dafs_n
       nd.score = cv.take<float>(1); nd.info = cv.take<uint32_t>(16); nd.fstate = cv.take<float>(4);
       if (pass == 0) {
         cv.base = c->dd_alloc(cv.used + 256);
-        if (!cv.base) return undo(DAFS_HIP_ENOMEM);
+        if (!cv.base) return DAFS_HIP_ENOMEM;
         blk0[b] = cv.base; blk0_bytes[b] = cv.used + 256;
       }
     }
@@ -383,6 +436,7 @@ int nodes_open(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const dafs_n
     }
   }
   int rc;
+  if (fail_injected(1)) return DAFS_HIP_ELAUNCH;
   if ((rc = ln.d_nodes->upload(nodes.data(), nnodes, ln.st))) return rc;  // synchronises: host vectors stay valid until here
   const mp_store_dev mpv = mps.view(c->d_len.ptr, nseq);
   const bp_store_dev bpv = bps.view();
@@ -404,6 +458,7 @@ int nodes_open(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const dafs_n
   std::vector<uint32_t> counts(nnodes);
   if (hip_check(hipMemcpyAsync(counts.data(), ln.d_paused->ptr, (size_t)nnodes * 4, hipMemcpyDeviceToHost, ln.st))) return DAFS_HIP_ELAUNCH;
   if (hip_check(hipStreamSynchronize(ln.st))) return DAFS_HIP_ELAUNCH;
+  if (fail_injected(2)) return DAFS_HIP_ELAUNCH;
   for (uint32_t b = 0; b < nnodes; ++b) {
     const uint32_t ncbp = counts[b];
     carver cb;
@@ -414,21 +469,51 @@ int nodes_open(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const dafs_n
       nodes[b].sw = cb.take<float>((size_t)ncbp + 1);
       if (pass == 0) {
         cb.base = c->dd_alloc(cb.used + 256);
-        if (!cb.base) return undo(DAFS_HIP_ENOMEM);
+        if (!cb.base) return DAFS_HIP_ENOMEM;
         blk1[b] = cb.base; blk1_bytes[b] = cb.used + 256;
       }
     }
   }
+  if (fail_injected(3)) return DAFS_HIP_ELAUNCH;
+  for (uint32_t b = 0; b < nnodes; ++b)  // both placements a launch may choose for this node, before anything runs on it
+    if ((rc = plan_check(nodes[b], false))) return rc;
   if ((rc = ln.d_nodes->upload(nodes.data(), nnodes, ln.st))) return rc;
   if ((rc = dd_cbp_fill_launch(ln.d_nodes->ptr, nnodes, force_wide ? 0 : max_len, dp, ln.st))) return rc;
-  for (uint32_t b = 0; b < nnodes; ++b) c->dd_open.push_back({nodes[b], lds[b], split_lds[b], false, {blk0[b], blk1[b]}, {blk0_bytes[b], blk1_bytes[b]}, false, false, {}});
+  if (fail_injected(4)) return DAFS_HIP_ELAUNCH;
+  for (uint32_t b = 0; b < nnodes; ++b) {
+    dafs_hip_ctx::dd_open_node on;
+    on.nd = nodes[b]; on.lds = lds[b]; on.split_lds = split_lds[b];
+    on.blk[0] = blk0[b]; on.blk[1] = blk1[b]; on.blk_bytes[0] = blk0_bytes[b]; on.blk_bytes[1] = blk1_bytes[b];
+    c->dd_open.push_back(on);
+  }
   return DAFS_HIP_OK;
+}
+
+// A failed open leaves nothing behind: the fills, uploads and set-up kernels it has queued on the lane's stream may still
+// write into the blocks it carved, so the stream is drained before they go back to the free list (the next dd_alloc,
+// possibly for the other lane, may hand them out at once), and the nodes it may have appended are dropped.
+int nodes_open(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const dafs_node_input* in, const dd_params& dp) {
+  const size_t first = c->dd_open.size();
+  open_blocks ob;
+  const int rc = nodes_open_impl(c, ln, nnodes, in, dp, ob);
+  if (rc) {
+    (void)hipStreamSynchronize(ln.st);
+    c->dd_open.resize(first);
+    for (size_t b = 0; b < ob.blk0.size(); ++b) { c->dd_free(ob.blk0[b], ob.bytes0[b]); c->dd_free(ob.blk1[b], ob.bytes1[b]); }
+  }
+  return rc;
 }
 
 // One launch of the subgradient loop over the given resident nodes; finished[k] tells which of them are done.
 // In two halves, so that launches on two lanes can be in flight together: advance_launch enqueues the kernel and the
 // copy of the per-node words, advance_collect waits for them.
-struct advance_state { std::vector<uint32_t> who, handles, off; const uint32_t* paused = nullptr; const uint32_t* packed = nullptr; bool launched = false; };
+struct advance_state {
+  std::vector<uint32_t> who, handles, off;
+  const uint32_t* paused = nullptr;
+  const uint32_t* packed = nullptr;
+  bool launched = false;  // the solver may be running: collect must wait for the lane
+  bool complete = false;  // ... and the per-node words are on their way to the landing place
+};
 
 int advance_launch(dafs_hip_ctx* c, const dd_lane& ln, uint32_t n, const uint32_t* handles, dd_params dp, uint32_t max_iterations, uint8_t* finished,
                    advance_state& stt) {
@@ -437,6 +522,7 @@ int advance_launch(dafs_hip_ctx* c, const dd_lane& ln, uint32_t n, const uint32_
   who.clear();
   stt.handles.assign(handles, handles + n);
   stt.launched = false;
+  stt.complete = false;
   size_t lds_max = 0;
   for (uint32_t k = 0; k < n; ++k) {
     if (handles[k] >= c->dd_open.size()) return DAFS_HIP_EINVAL;
@@ -452,8 +538,10 @@ int advance_launch(dafs_hip_ctx* c, const dd_lane& ln, uint32_t n, const uint32_
   const char* split_env = getenv("DAFS_HIP_DD_SPLIT");
   const bool split_allowed = !(split_env && atoi(split_env) == 0);
   bool split = false;
-  // three workgroups per node, one per CU (their LDS does not leave room for a second): all of them must fit the device
-  if (split_allowed && (int)(nodes.size() * 3) <= c->num_cus - 16)
+  // three workgroups per node, one per CU (their LDS does not leave room for a second): all of them must fit the device,
+  // next to the workgroups of the other lane's launch when that one is still in flight (dafs_hip_nodes_round)
+  const uint32_t other_wgs = c->dd_wgs_in_flight[ln.id ^ 1];
+  if (split_allowed && (int)(nodes.size() * 3 + other_wgs) <= c->num_cus - 16)
     for (size_t b = 0; b < nodes.size(); ++b) split = split || (c->dd_open[handles[who[b]]].split_lds != 0 && !c->dd_open[handles[who[b]]].no_split);
   for (size_t b = 0; b < nodes.size(); ++b) {
     const dafs_hip_ctx::dd_open_node& on = c->dd_open[handles[who[b]]];
@@ -469,8 +557,13 @@ int advance_launch(dafs_hip_ctx* c, const dd_lane& ln, uint32_t n, const uint32_
   }
   dp.slice = max_iterations;
   int rc;
+  for (size_t b = 0; b < nodes.size(); ++b)  // the form each node takes in THIS launch against what its block holds
+    if ((rc = plan_check(nodes[b], nodes[b].split != 0))) return rc;
   if ((rc = ln.d_nodes->upload(nodes.data(), nodes.size(), ln.st))) return rc;
   if ((rc = ln.d_paused->reserve(nodes.size()))) return rc;
+  for (size_t b = 0; b < nodes.size(); ++b) c->dd_open[handles[who[b]]].in_flight = true;
+  c->dd_wgs_in_flight[ln.id] = (uint32_t)nodes.size() * (split ? 3u : 1u);
+  stt.launched = true;  // from here on advance_collect has something to wait for, whatever fails below
   if ((rc = dd_solve_launch(ln.d_nodes->ptr, (uint32_t)nodes.size(), dp, lds_max, split, ln.d_paused->ptr, ln.st))) return rc;
   // the result words of every node of the launch come along (one packed copy): a node that finishes here needs no
   // copy and no synchronisation of its own in dafs_hip_nodes_result
@@ -490,22 +583,25 @@ int advance_launch(dafs_hip_ctx* c, const dd_lane& ln, uint32_t n, const uint32_
   stt.packed = landing + 2 * nodes.size();
   if (hip_check(hipMemcpyAsync(landing, ln.d_paused->ptr, nodes.size() * 4, hipMemcpyDeviceToHost, ln.st))) return DAFS_HIP_ELAUNCH;
   if (total && hip_check(hipMemcpyAsync(landing + 2 * nodes.size(), d_pack.ptr, total * 4, hipMemcpyDeviceToHost, ln.st))) return DAFS_HIP_ELAUNCH;
-  stt.launched = true;
+  stt.complete = true;
   return DAFS_HIP_OK;
 }
 
 int advance_collect(dafs_hip_ctx* c, const dd_lane& ln, advance_state& stt, uint8_t* finished) {
   if (!stt.launched) return DAFS_HIP_OK;
-  if (hip_check(hipStreamSynchronize(ln.st))) return DAFS_HIP_ELAUNCH;
+  const bool sync_failed = hip_check(hipStreamSynchronize(ln.st));
+  c->dd_wgs_in_flight[ln.id] = 0;
+  for (size_t b = 0; b < stt.who.size(); ++b) c->dd_open[stt.handles[stt.who[b]]].in_flight = false;
+  stt.launched = false;
+  if (sync_failed || !stt.complete) return DAFS_HIP_ELAUNCH;  // a launch that failed half-way: its nodes stay unfinished
   for (size_t b = 0; b < stt.who.size(); ++b) {
     const uint32_t h = stt.handles[stt.who[b]];
     const bool done = stt.paused[b] == 0;
-    if (stt.paused[b] == 2) c->dd_open[h].no_split = true;  // its folders were lost: from now on the one-workgroup form
+    if (stt.paused[b] == 2 && !c->dd_open[h].no_split) { c->dd_open[h].no_split = true; ++c->dd_demotions; }  // its folders were lost: from now on the one-workgroup form
     c->dd_open[h].finished = done;
     if (done) c->dd_open[h].result.assign(stt.packed + stt.off[b], stt.packed + stt.off[b + 1]);
     if (finished) finished[stt.who[b]] = done ? 1 : 0;
   }
-  stt.launched = false;
   return DAFS_HIP_OK;
 }
 
@@ -513,11 +609,12 @@ int nodes_advance(dafs_hip_ctx* c, uint32_t n, const uint32_t* handles, dd_param
   advance_state stt;
   const dd_lane ln = lane_of(c, 0);
   const int rc = advance_launch(c, ln, n, handles, dp, max_iterations, finished, stt);
-  return rc ? rc : advance_collect(c, ln, stt, finished);
+  const int rc2 = advance_collect(c, ln, stt, finished);  // also after a failure: whatever was enqueued is waited for
+  return rc ? rc : rc2;
 }
 
 int nodes_result(dafs_hip_ctx* c, uint32_t handle, dafs_node_output* out, bool stamps) {
-  if (handle >= c->dd_open.size() || !c->dd_open[handle].finished || c->dd_open[handle].released) return DAFS_HIP_EINVAL;
+  if (handle >= c->dd_open.size() || !c->dd_open[handle].finished || c->dd_open[handle].released || c->dd_open[handle].in_flight) return DAFS_HIP_EINVAL;
   const dd_node& nd = c->dd_open[handle].nd;
   uint32_t info[16];
   float score = 0.0f;
@@ -544,9 +641,17 @@ int nodes_result(dafs_hip_ctx* c, uint32_t handle, dafs_node_output* out, bool s
   out->ncbp = info[0];
   out->iterations = info[1];
   out->violated = info[2];
-  {  // the node's device memory is free for the nodes opened from now on (work on one stream: ordered behind this copy)
+  {  // The node's device memory is free for the nodes opened from now on.  Nothing can still use it: a node only becomes
+     // `finished` in advance_collect, after its lane's stream has been drained, and a finished node is in no later launch.
+     // No other open node may lie in the range (the free list would hand it out a second time).
     dafs_hip_ctx::dd_open_node& on = c->dd_open[handle];
-    for (int k = 0; k < 2; ++k) c->dd_free(on.blk[k], on.blk_bytes[k]);
+    for (int k = 0; k < 2; ++k) {
+      if (on.blk[k] && c->dd_range_live(on.blk[k], on.blk_bytes[k], &on)) {
+        fprintf(stderr, "dafs_hip: node %u shares device memory with another open node\n", handle);
+        return DAFS_HIP_ELAUNCH;
+      }
+      c->dd_free(on.blk[k], on.blk_bytes[k]);
+    }
     on.released = true;
   }
   return info[3] ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;  // info[3]: the alignment traceback left the envelope
@@ -565,7 +670,7 @@ extern "C" int dafs_hip_nodes_open(dafs_hip_ctx* c, uint32_t nnodes, const dafs_
   if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
   const uint32_t first = (uint32_t)c->dd_open.size();
   const int rc = nodes_open(c, lane_of(c, 0), nnodes, in, device_params(prm));
-  if (rc) { c->dd_open.resize(first); return rc; }
+  if (rc) return rc;
   for (uint32_t b = 0; b < nnodes; ++b) handles[b] = first + b;
   return DAFS_HIP_OK;
 }
@@ -600,7 +705,10 @@ extern "C" int dafs_hip_nodes_round(dafs_hip_ctx* c, uint32_t n_new, const dafs_
       dp.t_ref = c->d_tref.ptr;
       dp.t_ref_write = 1;
     }
-    if ((rc = advance_launch(c, l0, n_old, old_handles, dp, max_iterations, finished_old, st_old))) return rc;
+    if ((rc = advance_launch(c, l0, n_old, old_handles, dp, max_iterations, finished_old, st_old))) {
+      (void)advance_collect(c, l0, st_old, finished_old);  // whatever part of the launch was enqueued is waited for
+      return rc;
+    }
   }
   if (n_new) {
     const uint32_t first = (uint32_t)c->dd_open.size();
@@ -608,7 +716,7 @@ extern "C" int dafs_hip_nodes_round(dafs_hip_ctx* c, uint32_t n_new, const dafs_
     dpn.t_ref_write = 0;  // a late starter takes the round's reference tick (none when it runs alone)
     if (!n_old) dpn.t_ref = nullptr;
     rc = nodes_open(c, l1, n_new, in, dpn);
-    if (rc) { c->dd_open.resize(first); (void)advance_collect(c, l0, st_old, finished_old); return rc; }
+    if (rc) { (void)advance_collect(c, l0, st_old, finished_old); return rc; }
     for (uint32_t b = 0; b < n_new; ++b) new_handles[b] = first + b;
     rc = advance_launch(c, l1, n_new, new_handles, dpn, max_iterations, finished_new, st_new);
   }
@@ -628,6 +736,12 @@ extern "C" int dafs_hip_nodes_close(dafs_hip_ctx* c) {
   if (hip_check(hipSetDevice(c->device))) return DAFS_HIP_ENODEV;
   if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;
   c->dd_reset();
+  return DAFS_HIP_OK;
+}
+
+extern "C" int dafs_hip_nodes_demotions(dafs_hip_ctx* c, uint32_t* n) {
+  if (!c || !n) return DAFS_HIP_EINVAL;
+  *n = c->dd_demotions;
   return DAFS_HIP_OK;
 }
 

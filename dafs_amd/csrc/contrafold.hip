@@ -21,6 +21,7 @@
 #include "contra_math.h"
 #include "contrafold.h"
 #include "hip_util.h"
+#include "stage.h"
 
 namespace dafs {
 
@@ -862,9 +863,9 @@ int contrafold_launch(const cf_batch& B, uint32_t nseq, uint32_t max_len, hipStr
     const int v = atoi(e);
     if (v >= 64 && v <= CF_FOLD_THREADS && v % 64 == 0) fold_threads = v;
   }
-  hipLaunchKernelGGL(k_contrafold, dim3(nseq), dim3(fold_threads), lds, st, B, use_ring, pool_floats, cell_waves, pool_bufs);
+  STAGE_LAUNCH(ST_CONTRAFOLD, st) hipLaunchKernelGGL(k_contrafold, dim3(nseq), dim3(fold_threads), lds, st, B, use_ring, pool_floats, cell_waves, pool_bufs);
   if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
-  hipLaunchKernelGGL(k_contrafold_posterior, dim3(max_len + 1, nseq), dim3(CF_THREADS), ints, st, B);
+  STAGE_LAUNCH(ST_CF_POSTERIOR, st) hipLaunchKernelGGL(k_contrafold_posterior, dim3(max_len + 1, nseq), dim3(CF_THREADS), ints, st, B);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 
@@ -872,7 +873,7 @@ int bp_compact_launch(const cf_batch& B, uint32_t nseq, float th, const uint64_t
                       float* out_val, uint64_t* out_off, uint32_t* out_nnz, unsigned long long* pool_top, uint64_t pool_cap, int* status,
                       hipStream_t st) {
   if (!nseq) return DAFS_HIP_OK;
-  hipLaunchKernelGGL(k_bp_compact, dim3(nseq), dim3(256), 0, st, B, th, rp_off, out_rowptr, out_col, out_val, out_off, out_nnz, pool_top,
+  STAGE_LAUNCH(ST_BP_COMPACT, st) hipLaunchKernelGGL(k_bp_compact, dim3(nseq), dim3(256), 0, st, B, th, rp_off, out_rowptr, out_col, out_val, out_off, out_nnz, pool_top,
                      pool_cap, status);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }

@@ -12,6 +12,7 @@
 #include "hip_util.h"
 #include "sparse_view.h"
 #include "dd.h"
+#include "stage.h"
 
 namespace dafs {
 
@@ -125,6 +126,7 @@ struct dafs_hip_ctx {
   dafs::dev_buf<int> cf_iws, cf_cons;
   dafs::dev_buf<float> cf_fws, cf_post, cf_logz;
   dafs::dev_buf<unsigned long long> cf_stamps;
+  dafs::stage_recorder stages;  // dafs_hip_stage_timing / _report
   // progressive phase workspaces
   dafs::dev_buf<uint8_t> work, work2;
   dafs::dev_buf<dafs::dd_node> d_nodes;
@@ -154,9 +156,29 @@ struct dafs_hip_ctx {
   std::vector<dd_chunk> dd_chunks;
   std::map<uint8_t*, size_t> dd_free_blocks;  // start -> bytes
   size_t dd_in_use = 0, dd_peak = 0;
-  struct dd_open_node { dafs::dd_node nd; size_t lds, split_lds; bool finished; uint8_t* blk[2]; size_t blk_bytes[2]; bool released;
-                        bool no_split; std::vector<uint32_t> result; };  // result: the node's result words, brought along by the launch it finished in  // no_split: a launch lost this node's folding workgroups once (k_dd_solve), keep it on one workgroup
+  struct dd_open_node {
+    dafs::dd_node nd;
+    size_t lds = 0, split_lds = 0;
+    bool finished = false;
+    uint8_t* blk[2] = {nullptr, nullptr};
+    size_t blk_bytes[2] = {0, 0};
+    bool released = false;   // its blocks went back to the free list (dafs_hip_nodes_result)
+    bool no_split = false;   // a launch lost this node's folding workgroups once (k_dd_solve): keep it on one workgroup
+    bool in_flight = false;  // part of a launch that has not been collected yet: its blocks must not be freed
+    std::vector<uint32_t> result;  // the node's result words, brought along by the launch it finished in
+  };
   std::vector<dd_open_node> dd_open;
+  uint32_t dd_wgs_in_flight[2] = {0, 0};  // per lane: workgroups of the uncollected launch (split launches of both lanes must fit the device together)
+  uint32_t dd_demotions = 0;              // nodes whose folders were lost and that went on in the one-workgroup form (since nodes_close)
+  // true when [p, p + bytes) overlaps a block of an open node that has not been released (a free of such a range is a bug)
+  bool dd_range_live(const uint8_t* p, size_t bytes, const dd_open_node* except) const {
+    for (const dd_open_node& on : dd_open) {
+      if (&on == except || on.released) continue;
+      for (int k = 0; k < 2; ++k)
+        if (on.blk[k] && p < on.blk[k] + on.blk_bytes[k] && on.blk[k] < p + bytes) return true;
+    }
+    return false;
+  }
   void dd_free(uint8_t* p, size_t bytes) {
     if (!p || !bytes) return;
     bytes = (bytes + 255) & ~(size_t)255;
@@ -211,6 +233,8 @@ struct dafs_hip_ctx {
     for (dd_chunk& ch : dd_chunks) dd_free_blocks.emplace(ch.ptr, ch.cap);
     dd_in_use = 0;
     dd_open.clear();
+    dd_wgs_in_flight[0] = dd_wgs_in_flight[1] = 0;
+    dd_demotions = 0;
   }
   void dd_release() { for (dd_chunk& ch : dd_chunks) (void)hipFree(ch.ptr); dd_chunks.clear(); dd_free_blocks.clear(); dd_in_use = 0; dd_open.clear(); }
   uint32_t max_len() const { uint32_t m = 0; for (uint32_t l : len) m = l > m ? l : m; return m; }

@@ -31,6 +31,7 @@
 #include "../../include/dafs_hip.h"
 #include "dd.h"
 #include "hip_util.h"
+#include "stage.h"
 
 namespace dafs {
 
@@ -1496,7 +1497,14 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_cbp_fill(const dd_node* nod
 // runs DP + traceback, publishes the score and raises its counter.  All waits are bounded.
 // ------------------------------------------------------------------------------------------
 #define DD_SYNC_EXIT 0xFFFFFFFFu
-#define DD_SPIN_LIMIT (1u << 22)
+// How long one side of a split node waits for the other before it takes it for lost, in wall_clock64 ticks (100 MHz):
+// two seconds plus 40 ns per cell of the wider folding -- ten times what a pass of the span-ordered form on HBM tables
+// costs (6.5 ms at 1100 columns, 26 ms at 2650: ~3.7 ns per cell), so that the folders of the widest nodes (11 500 columns:
+// ~0.5 s a pass) are not declared lost while they work.
+__device__ __forceinline__ unsigned long long dd_lost_ticks(uint32_t L1, uint32_t L2) {
+  const unsigned long long L = L1 > L2 ? L1 : L2;
+  return 200000000ull + 4ull * L * L;
+}
 __device__ __forceinline__ uint32_t sync_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sync_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -1533,9 +1541,10 @@ __device__ __forceinline__ void dd_folder(const dd_node& nd, const dd_params& pr
   else if (nd.fold_fast & (isx ? 4u : 8u)) { ring = (float*)s_dd; lck = (uint32_t*)(ring + dd_ring_words(L)); P = ring; }  // codes in HBM
   for (uint32_t it = t_first;; ++it) {
     if (tid == 0) {
-      uint32_t g = 0, spins = 0;
-      while ((g = sync_load(&nd.sync[0])) != it + 1 && g != DD_SYNC_EXIT && ++spins < DD_SPIN_LIMIT) __builtin_amdgcn_s_sleep(16);
-      s_go = (g == it + 1) ? 1u : 0u;
+      uint32_t g = 0;
+      const unsigned long long t_wait = wall_clock64(), t_max_wait = dd_lost_ticks(nd.L1, nd.L2);
+      while ((g = sync_load(&nd.sync[0])) != it + 1 && g != DD_SYNC_EXIT && wall_clock64() - t_wait <= t_max_wait) __builtin_amdgcn_s_sleep(16);
+      s_go = (g == it + 1) ? 1u : 0u;  // a leader that does not show up in time: leave (it will find its folders lost and be relaunched)
     }
     __syncthreads();
     if (!s_go) break;
@@ -1836,14 +1845,14 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
       if (split && fold_on) {
         // Collect the two foldings.  The wait is bounded in time (wall_clock64, 100 MHz), not in spins: split mode only
         // works while the node's three workgroups are on the machine together, and a kernel on another stream, a second
-        // context or a masked device can keep the folders off it.  A folder that has not answered after two seconds is
-        // taken for lost: nothing of iteration t has been applied yet (the multiplier updates follow), so the node is
+        // context or a masked device can keep the folders off it.  A folder that has not answered after dd_lost_ticks (two
+        // seconds + ten times the cost of its pass) is taken for lost: nothing of iteration t has been applied yet (the multiplier updates follow), so the node is
         // parked at t like a node whose slice ran out, marked for the one-workgroup form, and the host relaunches it.
-        const unsigned long long t_wait = wall_clock64();
+        const unsigned long long t_wait = wall_clock64(), t_max_wait = dd_lost_ticks(L1, L2);
         bool lost = prm.debug_lose_folders != 0;  // tests: take the recovery path without waiting
         while (!lost && (sync_load(&nd.sync[1]) != t + 1 || sync_load(&nd.sync[2]) != t + 1)) {
           __builtin_amdgcn_s_sleep(16);
-          if (wall_clock64() - t_wait > 200000000ull) lost = true;
+          if (wall_clock64() - t_wait > t_max_wait) lost = true;
         }
         if (lost) s_lost = 1;
         s_score[0] = __uint_as_float(nd.sync[3]);
@@ -2050,9 +2059,9 @@ int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_
   // coop: four wavefronts per workgroup (the p_x / p_y rows keep a wavefront each, four rows per workgroup; a p_z row
   // takes the whole workgroup, so the grid has a workgroup per row of the longest alignment)
   if (coop && rows == 4) {
-    hipLaunchKernelGGL(k_node_avg, dim3(max_len, nnodes, 3), dim3(256), lds, st, d_nodes, mp, bp, row_cap, 1u);
+    STAGE_LAUNCH(ST_NODE_AVG, st) hipLaunchKernelGGL(k_node_avg, dim3(max_len, nnodes, 3), dim3(256), lds, st, d_nodes, mp, bp, row_cap, 1u);
   } else {
-    hipLaunchKernelGGL(k_node_avg, dim3((max_len + rows - 1) / rows, nnodes, 3), dim3(64 * rows), lds, st, d_nodes, mp, bp, row_cap, 0u);
+    STAGE_LAUNCH(ST_NODE_AVG, st) hipLaunchKernelGGL(k_node_avg, dim3((max_len + rows - 1) / rows, nnodes, 3), dim3(64 * rows), lds, st, d_nodes, mp, bp, row_cap, 0u);
   }
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
@@ -2065,7 +2074,7 @@ int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, 
   if (rc) return rc;
   // four workgroups per node when the launch is small (the nodes of the tree's critical chain are opened one or two at a time)
   const uint32_t parts = (nnodes <= 16 && !getenv("DAFS_HIP_DD_LISTS1")) ? 4u : 1u;  // the env switch is a tuning aid
-  hipLaunchKernelGGL(k_node_lists, dim3(nnodes, parts), dim3(DD_THREADS), lds, st, d_nodes, prm, d_ncbp, (uint32_t)lds, parts);
+  STAGE_LAUNCH(ST_NODE_LISTS, st) hipLaunchKernelGGL(k_node_lists, dim3(nnodes, parts), dim3(DD_THREADS), lds, st, d_nodes, prm, d_ncbp, (uint32_t)lds, parts);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, dd_params prm, hipStream_t st) {
@@ -2075,7 +2084,7 @@ int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len
   if (lds > budget) lds = budget;
   int rc = lds_optin((const void*)k_node_cbp_fill, 2, lds, budget);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_node_cbp_fill, dim3(nnodes), dim3(DD_THREADS), lds, st, d_nodes, prm, (uint32_t)lds);
+  STAGE_LAUNCH(ST_NODE_CBP_FILL, st) hipLaunchKernelGGL(k_node_cbp_fill, dim3(nnodes), dim3(DD_THREADS), lds, st, d_nodes, prm, (uint32_t)lds);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 // The result words of every node of a launch (x, y, z, score, info: carved back to back in the node's block) gathered
@@ -2089,7 +2098,7 @@ __global__ __launch_bounds__(256) void k_node_pack(const dd_node* nodes, const u
 }
 int dd_pack_launch(const dd_node* d_nodes, uint32_t nnodes, const uint32_t* d_off, uint32_t* d_out, hipStream_t st) {
   if (!nnodes) return DAFS_HIP_OK;
-  hipLaunchKernelGGL(k_node_pack, dim3(nnodes), dim3(256), 0, st, d_nodes, d_off, d_out);
+  STAGE_LAUNCH(ST_NODE_PACK, st) hipLaunchKernelGGL(k_node_pack, dim3(nnodes), dim3(256), 0, st, d_nodes, d_off, d_out);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 
@@ -2101,11 +2110,11 @@ int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size
     if (rc) return rc;
   }
   // split mode needs the three workgroups of a node on the machine together: the caller keeps 3 * nnodes within the CU count
-  hipLaunchKernelGGL(k_dd_solve, dim3(nnodes, split ? 3 : 1), dim3(DD_SOLVE_THREADS), lds_bytes, st, d_nodes, prm, d_paused);
+  STAGE_LAUNCH(ST_DD_SOLVE, st) hipLaunchKernelGGL(k_dd_solve, dim3(nnodes, split ? 3 : 1), dim3(DD_SOLVE_THREADS), lds_bytes, st, d_nodes, prm, d_paused);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 int nussinov_launch(uint32_t L, const float* p, const float* q, float w, float th, nuss_ws ws, uint32_t* ss, float* score, hipStream_t st) {
-  hipLaunchKernelGGL(k_nussinov_single, dim3(1), dim3(DD_THREADS), 0, st, L, p, q, w, th, ws, ss, score);
+  STAGE_LAUNCH(ST_NUSSINOV_SINGLE, st) hipLaunchKernelGGL(k_nussinov_single, dim3(1), dim3(DD_THREADS), 0, st, L, p, q, w, th, ws, ss, score);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 int nussinov_dense_launch(uint32_t L, const float* p, const float* q, float w, float th, float* dp, uint32_t* tr, uint32_t* stack, uint32_t* ss,
@@ -2115,7 +2124,7 @@ int nussinov_dense_launch(uint32_t L, const float* p, const float* q, float w, f
 }
 int nw_launch(uint32_t L1, uint32_t L2, const float* p, const float* q, float th, uint32_t* env, int compute_env,
               float* dp, uint8_t* tr, uint32_t* al, float* score, hipStream_t st) {
-  hipLaunchKernelGGL(k_nw_single, dim3(1), dim3(DD_THREADS), 0, st, L1, L2, p, q, th, env, compute_env, dp, tr, al, score);
+  STAGE_LAUNCH(ST_NW_SINGLE, st) hipLaunchKernelGGL(k_nw_single, dim3(1), dim3(DD_THREADS), 0, st, L1, L2, p, q, th, env, compute_env, dp, tr, al, score);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 

@@ -31,6 +31,7 @@
 #include "../../include/dafs_hip.h"
 #include "pc_math.h"
 #include "hip_util.h"
+#include "stage.h"
 #include "pair_sweeps.h"
 
 namespace dafs {
@@ -405,6 +406,8 @@ extern "C" int dafs_hipk_pairhmm3_launch(const dafs_pairhmm3_args* args, const d
   }
   uint32_t steps = plan->slab_steps, cap = rp_cap;
   void* params[] = {&a, &steps, &cap};
-  if (hip_check(hipLaunchKernel(v->fn, dim3(plan->nwaves / 4), dim3(256), params, lds, (hipStream_t)hip_stream))) return DAFS_HIP_ELAUNCH;
+  hipError_t launch_err = hipSuccess;
+  STAGE_LAUNCH(dafs::ST_PAIRHMM3, (hipStream_t)hip_stream) launch_err = hipLaunchKernel(v->fn, dim3(plan->nwaves / 4), dim3(256), params, lds, (hipStream_t)hip_stream);
+  if (hip_check(launch_err)) return DAFS_HIP_ELAUNCH;
   return DAFS_HIP_OK;
 }

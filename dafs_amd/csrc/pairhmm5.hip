@@ -22,6 +22,7 @@
 #include "../../include/dafs_hip.h"
 #include "contra_math.h"
 #include "hip_util.h"
+#include "stage.h"
 #include "pair_sweeps.h"
 
 namespace dafs {
@@ -310,6 +311,8 @@ extern "C" int dafs_hipk_pairhmm5_launch(const dafs_pairhmm5_args* args, const d
   dafs_pairhmm5_args a = *args;
   uint32_t steps = plan->slab_steps, cap = rp_cap;
   void* params[] = {&a, &steps, &cap};
-  if (hip_check(hipLaunchKernel(v->fn, dim3(plan->nwaves / 4), dim3(256), params, lds, (hipStream_t)hip_stream))) return DAFS_HIP_ELAUNCH;
+  hipError_t launch_err = hipSuccess;
+  STAGE_LAUNCH(dafs::ST_PAIRHMM5, (hipStream_t)hip_stream) launch_err = hipLaunchKernel(v->fn, dim3(plan->nwaves / 4), dim3(256), params, lds, (hipStream_t)hip_stream);
+  if (hip_check(launch_err)) return DAFS_HIP_ELAUNCH;
   return DAFS_HIP_OK;
 }

@@ -16,6 +16,7 @@
 #include <stdint.h>
 #include "../../include/dafs_hip.h"
 #include "hip_util.h"
+#include "stage.h"
 #include "sparse_view.h"
 #include "pct.h"
 
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(256) void k_mp_sim(mp_store_dev in, const uint32_t*
 int mp_sim_launch(mp_store_dev in, const uint32_t* pair_x, const uint32_t* pair_y, uint32_t npairs, float* task_sim, float* row_dp, int* row_tr,
                   hipStream_t st) {
   if (!npairs) return DAFS_HIP_OK;
-  hipLaunchKernelGGL(k_mp_sim, dim3((npairs + 255) / 256), dim3(256), 0, st, in, pair_x, pair_y, npairs, task_sim, row_dp, row_tr);
+  STAGE_LAUNCH(ST_MP_SIM, st) hipLaunchKernelGGL(k_mp_sim, dim3((npairs + 255) / 256), dim3(256), 0, st, in, pair_x, pair_y, npairs, task_sim, row_dp, row_tr);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 
@@ -682,16 +683,16 @@ int pct_ident_launch(uint2* ident2, uint32_t n, hipStream_t st) {
 int pct_interleave_launch(const uint32_t* col, const float* val, uint2* ent2, uint64_t n, hipStream_t st) {
   if (!n) return DAFS_HIP_OK;
   const uint64_t blocks = (n + 255) / 256;
-  hipLaunchKernelGGL(k_mp_interleave, dim3((uint32_t)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, col, val, ent2, n);
+  STAGE_LAUNCH(ST_MP_INTERLEAVE, st) hipLaunchKernelGGL(k_mp_interleave, dim3((uint32_t)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, col, val, ent2, n);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 
 int pct_fourway_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint32_t count, hipStream_t st) {
   if (!count) return DAFS_HIP_OK;
   a.max_len = max_len;
-  hipLaunchKernelGGL(k_fourway_rows, dim3(count), dim3(256), 0, st, a, pair0);
+  STAGE_LAUNCH(ST_FOURWAY_ROWS, st) hipLaunchKernelGGL(k_fourway_rows, dim3(count), dim3(256), 0, st, a, pair0);
   if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
-  hipLaunchKernelGGL(k_pct_emit, dim3(count), dim3(256), (size_t)2 * (max_len + 2) * 4, st, a, pair0);
+  STAGE_LAUNCH(ST_PCT_EMIT, st) hipLaunchKernelGGL(k_pct_emit, dim3(count), dim3(256), (size_t)2 * (max_len + 2) * 4, st, a, pair0);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 
@@ -707,9 +708,9 @@ int pct_match_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint32_
   a.max_len = max_len;
   static bool attr[16] = {false};
   if (!lds_optin_once((const void*)k_pct_rows, (int)kPctLdsBytes, attr)) return DAFS_HIP_ELAUNCH;
-  hipLaunchKernelGGL(k_pct_rows, dim3(count, (max_len + PCT_ROWS_PER_WG - 1) / PCT_ROWS_PER_WG), dim3(256), lds, st, a, pair0, row_cap);
+  STAGE_LAUNCH(ST_PCT_ROWS, st) hipLaunchKernelGGL(k_pct_rows, dim3(count, (max_len + PCT_ROWS_PER_WG - 1) / PCT_ROWS_PER_WG), dim3(256), lds, st, a, pair0, row_cap);
   if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
-  hipLaunchKernelGGL(k_pct_emit, dim3(count), dim3(256), (size_t)2 * (max_len + 2) * 4, st, a, pair0);
+  STAGE_LAUNCH(ST_PCT_EMIT, st) hipLaunchKernelGGL(k_pct_emit, dim3(count), dim3(256), (size_t)2 * (max_len + 2) * 4, st, a, pair0);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 
@@ -724,9 +725,9 @@ int pct_bp_launch(pct_bp_args a, uint32_t max_len, hipStream_t st) {
   a.max_len = max_len;
   static bool attr[16] = {false};
   if (!lds_optin_once((const void*)k_pct_bp_rows, (int)kPctLdsBytes, attr)) return DAFS_HIP_ELAUNCH;
-  hipLaunchKernelGGL(k_pct_bp_rows, dim3(a.mp.nseq, (max_len + PCT_ROWS_PER_WG - 1) / PCT_ROWS_PER_WG), dim3(256), lds, st, a, row_cap);
+  STAGE_LAUNCH(ST_PCT_BP_ROWS, st) hipLaunchKernelGGL(k_pct_bp_rows, dim3(a.mp.nseq, (max_len + PCT_ROWS_PER_WG - 1) / PCT_ROWS_PER_WG), dim3(256), lds, st, a, row_cap);
   if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
-  hipLaunchKernelGGL(k_pct_bp_emit, dim3(a.mp.nseq), dim3(256), (size_t)(max_len + 2) * 4, st, a);
+  STAGE_LAUNCH(ST_PCT_BP_EMIT, st) hipLaunchKernelGGL(k_pct_bp_emit, dim3(a.mp.nseq), dim3(256), (size_t)(max_len + 2) * 4, st, a);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 

@@ -218,6 +218,7 @@ def _phase2(ctx, own, names, seqs, n, sim, score, left, right, t, w, eta0, t_max
                 del aln[left[i]], aln[right[i]]
             res.levels += 1
         res.dd_memory = ctx.nodes_memory()  # (reserved, in use, peak) bytes of the resident nodes
+        res.dd_demotions = ctx.nodes_demotions()  # split nodes that lost their folders (0 on an undisturbed device)
         ctx.nodes_close()
     root = 2 * n - 2
     sidx, mask = aln[root]

@@ -330,6 +330,9 @@ int dafs_hip_nodes_close(dafs_hip_ctx* ctx);
 /* Device memory of the resident nodes (diagnostics): bytes reserved from the device, bytes held by open nodes now, and
  * the largest value the latter has had.  A node's memory is returned when dafs_hip_nodes_result has copied it out. */
 int dafs_hip_nodes_memory(dafs_hip_ctx* ctx, uint64_t* reserved, uint64_t* in_use, uint64_t* peak);
+/* Split-mode nodes whose folding workgroups did not show up in time and that went on in the one-workgroup form since the
+ * last dafs_hip_nodes_close (diagnostics: results are unaffected, the run is slower; 0 on an undisturbed device). */
+int dafs_hip_nodes_demotions(dafs_hip_ctx* ctx, uint32_t* n);
 /* Final common structure of an alignment (src/dafs.cpp:1857-1871 without the RNAalifold term):
  * averaged base-pairing matrix -> SparseNussinov::decode(p,ss,str) with threshold th. */
 int dafs_hip_consensus_structure(dafs_hip_ctx* ctx, uint32_t n, uint32_t len, const uint32_t* seq, const uint8_t* mask,
@@ -341,6 +344,20 @@ int dafs_hip_consensus_structure(dafs_hip_ctx* ctx, uint32_t n, uint32_t len, co
  * puts on each of them, and the constrained posteriors are averaged; p_out receives the len x len matrix. */
 int dafs_hip_update_basepairing(dafs_hip_ctx* ctx, uint32_t n, uint32_t len, const uint32_t* seq, const uint8_t* mask,
                                 const uint32_t* ss, float* p_out);
+
+/* ---- measurement aid: device time per kernel (bench.py's "stages") ----
+ * dafs_hip_stage_timing(ctx, 1) makes every kernel launch of the library record a pair of HIP events on its stream
+ * (one context per process at a time); dafs_hip_stage_report waits for the device, adds the elapsed times up per kernel and
+ * starts the next interval; dafs_hip_stage_timing(ctx, 0) switches it off.  `ms` of kernels that ran beside others on
+ * different streams overlap: they are per-kernel durations, not a partition of the wall-clock. */
+typedef struct {
+  const char* kernel;   /* kernel name as in the rocprofv3 kernel trace (template arguments left out) */
+  double ms;            /* sum over the launches of the interval */
+  double longest_ms;    /* the longest single launch */
+  uint32_t launches;
+} dafs_stage_time;
+int dafs_hip_stage_timing(dafs_hip_ctx* ctx, int enable);
+int dafs_hip_stage_report(dafs_hip_ctx* ctx, dafs_stage_time* out, uint32_t cap, uint32_t* n);
 
 #ifdef __cplusplus
 }

@@ -70,7 +70,7 @@ void orc_transpose(const orc_csr* in, uint32_t ncol, orc_csr* out);
 
 /* Whole pipeline (DAFS::run dafs.cpp:1781-1889) on in-memory sequences. */
 typedef struct {
-  int align_model;   /* 0 ProbCons, 1 CONTRAlign            (-a) */
+  int align_model;   /* 0 ProbCons, 1 CONTRAlign (-a); 2 = mp supplied via orc_pipeline_set_mp (--align-aux) */
   int fold_model;    /* 0 CONTRAfold, 1 = bp supplied via orc_pipeline_set_bp (--fold-aux) */
   float w;           /* -w   default 4.0  */
   float eta0;        /* --eta default 0.5 */
@@ -92,6 +92,8 @@ orc_pipeline* orc_pipeline_new(const orc_params* prm, uint32_t N, const char* co
 void orc_pipeline_free(orc_pipeline* pl);
 /* --fold-aux equivalent: inject BP for sequence x (src/fold.cpp:230-278) */
 void orc_pipeline_set_bp(orc_pipeline* pl, uint32_t x, const uint32_t* rowptr, const uint32_t* col, const float* val);
+/* --align-aux equivalent: inject the rows of mp[x][y], x < y (src/align.cpp:190-247); needs prm.align_model == 2 */
+void orc_pipeline_set_mp(orc_pipeline* pl, uint32_t x, uint32_t y, const uint32_t* rowptr, const uint32_t* col, const float* val);
 /* phase 1: bp_, mp_ (+transposes), sim_, PCTs, tree  (dafs.cpp:1787-1830) */
 int orc_pipeline_phase1(orc_pipeline* pl);
 /* phase 2: progressive alignment + final SS (dafs.cpp:1835-1876) */

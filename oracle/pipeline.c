@@ -757,6 +757,18 @@ void orc_pipeline_set_bp(orc_pipeline* pl, uint32_t x, const uint32_t* rowptr, c
   memcpy(pl->bp[x].val, val, (size_t)rowptr[L] * sizeof(float));
 }
 
+/* --align-aux equivalent (AUXAlign, src/align.cpp:190-247): rows of mp[x][y], x < y, supplied by the caller; used with
+ * prm.align_model == 2.  The transpose is built in phase 1 as for a computed matrix. */
+void orc_pipeline_set_mp(orc_pipeline* pl, uint32_t x, uint32_t y, const uint32_t* rowptr, const uint32_t* col, const float* val) {
+  const uint32_t L = pl->len[x];
+  orc_csr* m = MP(pl, x, y);
+  orc_csr_free(m);
+  csr_alloc(m, L, rowptr[L]);
+  memcpy(m->rowptr, rowptr, ((size_t)L + 1) * sizeof(uint32_t));
+  memcpy(m->col, col, (size_t)rowptr[L] * sizeof(uint32_t));
+  memcpy(m->val, val, (size_t)rowptr[L] * sizeof(float));
+}
+
 /* DAFS::run, dafs.cpp:1787-1830 */
 int orc_pipeline_phase1(orc_pipeline* pl) {
   const uint32_t N = pl->N;
@@ -783,12 +795,16 @@ int orc_pipeline_phase1(orc_pipeline* pl) {
     for (uint32_t j = i + 1; j < N; ++j) {
       const uint32_t L1 = pl->len[i], L2 = pl->len[j];
       orc_csr* m = MP(pl, i, j);
-      orc_csr_free(m);
-      csr_alloc(m, L1, L1 * L2);
-      int rc = orc_align_calculate(pl->prm.align_model, pl->seqs[i], L1, pl->seqs[j], L2, pl->prm.th_a, m->rowptr, m->col, m->val);
-      if (rc < 0) return rc;
-      m->col = (uint32_t*)realloc(m->col, ((size_t)rc + 1) * sizeof(uint32_t));
-      m->val = (float*)realloc(m->val, ((size_t)rc + 1) * sizeof(float));
+      if (pl->prm.align_model == 2) { /* rows supplied through orc_pipeline_set_mp */
+        if (!m->rowptr || m->nrow != L1) return -3;
+      } else {
+        orc_csr_free(m);
+        csr_alloc(m, L1, L1 * L2);
+        int rc = orc_align_calculate(pl->prm.align_model, pl->seqs[i], L1, pl->seqs[j], L2, pl->prm.th_a, m->rowptr, m->col, m->val);
+        if (rc < 0) return rc;
+        m->col = (uint32_t*)realloc(m->col, ((size_t)rc + 1) * sizeof(uint32_t));
+        m->val = (float*)realloc(m->val, ((size_t)rc + 1) * sizeof(float));
+      }
       orc_csr_free(MP(pl, j, i));
       orc_transpose(m, L2, MP(pl, j, i));
     }

@@ -58,6 +58,7 @@ class Oracle:
         L.orc_pipeline_new.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
         L.orc_pipeline_free.argtypes = [C.c_void_p]
         L.orc_pipeline_set_bp.argtypes = [C.c_void_p, C.c_uint] + [C.c_void_p] * 3
+        L.orc_pipeline_set_mp.argtypes = [C.c_void_p, C.c_uint, C.c_uint] + [C.c_void_p] * 3
         L.orc_pipeline_phase1.argtypes = [C.c_void_p]
         L.orc_pipeline_phase2.argtypes = [C.c_void_p]
         L.orc_pipeline_output.restype = C.c_char_p
@@ -156,12 +157,13 @@ class Oracle:
             setattr(p, k, v)
         return p
 
-    def pipeline(self, names, seqs, prm=None, bp=None):
-        return Pipeline(self, names, seqs, prm or self.params(), bp)
+    def pipeline(self, names, seqs, prm=None, bp=None, mp=None):
+        """mp (with prm.align_model == 2): function (x, y) -> (rowptr, col, val) of mp[x][y], x < y"""
+        return Pipeline(self, names, seqs, prm or self.params(), bp, mp)
 
 
 class Pipeline:
-    def __init__(self, orc, names, seqs, prm, bp):
+    def __init__(self, orc, names, seqs, prm, bp, mp=None):
         self.o = orc
         self.N = len(seqs)
         self.lens = [len(s) for s in seqs]
@@ -173,6 +175,16 @@ class Pipeline:
                 rp = np.ascontiguousarray(rp, np.uint32); col = np.ascontiguousarray(col, np.uint32)
                 val = np.ascontiguousarray(val, np.float32)
                 orc.lib.orc_pipeline_set_bp(self.h, x, rp.ctypes.data, col.ctypes.data, val.ctypes.data)
+        if mp is not None:
+            for x in range(self.N):
+                for y in range(x + 1, self.N):
+                    self.set_mp(x, y, *mp(x, y))
+
+    def set_mp(self, x, y, rp, col, val):
+        rp = np.ascontiguousarray(rp, np.uint32); col = np.ascontiguousarray(col, np.uint32)
+        val = np.ascontiguousarray(val, np.float32)
+        assert len(rp) == self.lens[x] + 1 and len(col) == len(val) == int(rp[-1])
+        self.o.lib.orc_pipeline_set_mp(self.h, x, y, rp.ctypes.data, col.ctypes.data, val.ctypes.data)
 
     def phase1(self):
         rc = self.o.lib.orc_pipeline_phase1(self.h); assert rc == 0, rc

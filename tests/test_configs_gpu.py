@@ -166,9 +166,28 @@ def test_c5_whole_run_properties(which):
     widest = max(max(d) for d in a.dd_dims.values())
     if which == "random":
         assert widest > 4096                       # the case is what it claims to be
-        everything = sum(40 * (l1 * l1 + l2 * l2 + l1 * l2) for l1, l2 in a.dd_dims.values())  # ~40 bytes per cell of the three tables
-        assert a.dd_memory[1] == 0 and a.dd_memory[2] < everything / 2   # the arena held the open nodes, not the whole tree
+    _check_arena(a)
+    assert a.dd_demotions == 0                     # no split node lost its folders on an undisturbed device
     assert time.time() - t0 < 300
+
+
+def _node_bytes_bound(l1, l2):
+    """upper bound of a resident node's device memory from its dimensions (capi_dd.cpp nodes_open: per cell of the L x L
+    folding tables p, q 8 + flags 0.5 + id map 4 + Nussinov work arrays 16 + byte codes 0.5 + lists and counters 6 +
+    up to two score copies 8 = 43 bytes; per cell of the L1 x L2 alignment tables 38 bytes; row arrays and padding)"""
+    return 43 * (l1 * l1 + l2 * l2) + 38 * (l1 + 1) * (l2 + 1) + 4096 * (l1 + l2) + (1 << 16)
+
+
+def _check_arena(res):
+    """The arena's high-water mark is what the nodes open at the same time need: in a round the open nodes still hold
+    their blocks while the newly ready ones get theirs (pipeline.run records each round's node set), plus 36 bytes per
+    consensus base pair.  Stated from the open-node sets, not from the size of the whole tree."""
+    reserved, in_use, peak = res.dd_memory
+    assert in_use == 0
+    cbp = {i: v[2] for i, v in res.dd_log.items()}
+    expected = max(sum(_node_bytes_bound(l1, l2) + 36 * cbp[i] + 1024 for i, l1, l2 in nodes) for _, nodes in res.rounds)
+    assert peak <= expected, (peak, expected)
+    assert peak >= expected / 3, (peak, expected)   # and the bound is not vacuous
 
 
 # ---------------------------------------------------------------------------------------------- wide forms, limits, arena
@@ -225,8 +244,106 @@ def test_node_arena_returns_memory():
     recs = synth.random_set(96, 60, seed=8)
     names, seqs = [r[0] for r in recs], [r[1] for r in recs]
     res = pipeline.run(names, seqs)
-    reserved, in_use, peak = res.dd_memory
-    assert in_use == 0
-    widths = sorted((max(d) for d in res.dd_dims.values()), reverse=True)
-    everything = sum(40 * w * w for w in widths)       # ~40 L^2 bytes per node
-    assert peak < everything / 2 + (64 << 20)
+    _check_arena(res)
+    everything = sum(_node_bytes_bound(l1, l2) for l1, l2 in res.dd_dims.values())
+    assert res.dd_memory[2] < everything / 2           # far below what the whole tree would take
+
+
+def test_wide_contralign_nodes_at_the_round2_fault_shape(oracle):
+    """Concurrent nodes of 8 + 8 and 16 + 16 rows, ~800-1600 columns wide, over CONTRAlign rows, with consensus base pairs
+    and multiplier updates -- the shape at which round 2's c5 run hit a GPU memory-access fault (foldings
+    beyond 1024 columns have no register form and keep no sweep-order score copy; the multiplier updates wrote through
+    the null pointer as soon as such a node's folding predicted a base pair).  128 random sequences of ~400 nt give a
+    guide tree with eight 8 + 8 nodes and three 16 + 16 nodes at those widths; -t 0.05 makes their foldings predict
+    pairs (at the default 0.2 the averaged matrices of unrelated sequences stay below the threshold and such nodes end
+    after one pass).  Matching and base-pairing rows come from the device models (checked against the oracle elsewhere)
+    and are handed to the oracle pipeline as --align-aux / --fold-aux input, so that the oracle's share is the
+    consistency transforms, the tree and the progressive phase; t_max = 4 bounds its time."""
+    from dafs_amd import capi, pipeline
+    (names, seqs), _ = _sets(128, 400)
+    n = len(seqs)
+    kw = dict(t_max=4, th_s=0.05)
+    ctx = capi.Context(0)
+    try:
+        ctx.set_sequences(seqs)
+        ctx.fold_posteriors(0.01)
+        bp = [(r.copy(), c.copy(), v.copy()) for r, c, v in ctx.bp(0)]
+        res = ctx.align_posteriors(capi.ALIGN_CONTRALIGN, 0.01)
+        where = {(int(res.pair_x[p]), int(res.pair_y[p])): p for p in range(len(res))}
+        rows_of = [res.csr(where[(x, y)]) for x in range(n) for y in range(x + 1, n)]
+        mp = (np.array([len(r[1]) for r in rows_of], np.uint32), np.concatenate([r[0] for r in rows_of]),
+              np.concatenate([r[1] for r in rows_of]), np.concatenate([r[2] for r in rows_of]))
+        got = pipeline.run(names, seqs, ctx=ctx, bp=bp, mp=mp, skip_uncoupled_folds=False, **kw)   # resident nodes, in rounds
+        score, left, right = got.tree
+        rows = {}
+        def nrows(i):
+            if i not in rows:
+                rows[i] = 1 if left[i] < 0 else nrows(int(left[i])) + nrows(int(right[i]))
+            return rows[i]
+        info = {i: (nrows(int(left[i])), nrows(int(right[i])), got.dd_dims[i], got.dd_log[i][:3]) for i in got.dd_dims}
+        wide = "\n".join("%d: rows %d+%d columns %s (iterations, violated, ncbp) %s" % ((i,) + info[i]) for i in sorted(info) if sum(info[i][:2]) >= 16)
+        if os.path.isdir("gpurun_out"):
+            open("gpurun_out/r3_fault_shape_nodes.txt", "w").write(wide + "\n")
+        # the case is what it claims to be: the node shapes, and on them what faulted -- multiplier updates (consensus pairs,
+        # violated constraints, a second iteration) on nodes whose foldings have no register form (beyond 1024 columns)
+        busy = {i for i, (r1, r2, d, (its, viol, ncbp)) in info.items() if ncbp > 0 and its > 1 and viol > 0}
+        assert len([i for i in busy if info[i][:2] == (8, 8) and 700 <= min(info[i][2]) and max(info[i][2]) <= 1150]) >= 6, wide
+        assert len([i for i in busy if info[i][:2] == (16, 16) and min(info[i][2]) > 1024]) >= 3, wide
+        _check_arena(got)
+        t0 = time.time()
+        pl = oracle.pipeline(names, seqs, oracle.params(fold_model=1, align_model=2, th_s1=kw["th_s"], **kw), bp=bp,
+                             mp=lambda x, y: res.csr(where[(x, y)]))
+        pl.phase1(); pl.phase2()
+        want = pl.output()
+        it, vi = pl.dd_log()
+        secs = pl.seconds()
+        pl.close()
+        print("oracle: %.1f s (pct+tree %.1f, progressive %.1f)" % (time.time() - t0, secs[2], secs[3]))
+        assert got.output == want
+        assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
+        assert sorted(v[1] for v in got.dd_log.values()) == sorted(int(x) for x in vi)
+        lvl = pipeline.run(names, seqs, ctx=ctx, bp=bp, mp=mp, level_sync=True, skip_uncoupled_folds=False, **kw)  # the nodes of a level in ONE launch
+        assert lvl.output == want and lvl.dd_log == got.dd_log
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("stage", [1, 2, 3, 4])
+def test_failed_open_leaves_nothing_behind(stage):
+    """A dafs_hip_nodes_open that fails late (DAFS_HIP_DD_FAIL_OPEN injects DAFS_HIP_ELAUNCH after the blocks and their
+    fills are queued / after the lists / after the second blocks / at the very end) gives every block back once the
+    stream has drained: the arena's in-use figure returns to where it was, and the context then runs the same nodes."""
+    from dafs_amd import capi, pipeline
+    recs = synth.family_set(8, 60, seed=13)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    want = pipeline.run(names, seqs)
+    ctx = capi.Context(0)
+    try:
+        ctx.set_sequences(seqs)
+        ctx.fold_posteriors(0.01)
+        ctx.align_posteriors(capi.ALIGN_PROBCONS, 0.01, fetch=False)
+        ctx.consistency(0.25, 0.25)
+        prm = capi.dd_params()
+        one = lambda i: (np.array([i], np.uint32), np.ones((1, len(seqs[i])), np.uint8))
+        keep, _ = ctx.nodes_open([one(0) + one(1)], prm)          # an open node that must survive the failed call
+        before = ctx.nodes_memory()[1]
+        assert before > 0
+        os.environ["DAFS_HIP_DD_FAIL_OPEN"] = str(stage)
+        try:
+            with pytest.raises(capi.DafsHipError):
+                ctx.nodes_open([one(2) + one(3), one(4) + one(5)], prm)
+        finally:
+            os.environ.pop("DAFS_HIP_DD_FAIL_OPEN", None)
+        assert ctx.nodes_memory()[1] == before
+        hs, dims = ctx.nodes_open([one(2) + one(3)], prm)
+        assert hs == [keep[0] + 1]                                 # the failed call's handles were not consumed
+        assert all(ctx.nodes_advance(keep + hs, prm, 0))
+        for h, i, j in ((keep[0], 0, 1), (hs[0], 2, 3)):
+            o = ctx.nodes_result(h, len(seqs[i]), len(seqs[j]))
+            assert o["iterations"] >= 1
+        assert ctx.nodes_memory()[1] == 0
+        ctx.nodes_close()
+        again = pipeline.run(names, seqs, ctx=ctx)
+        assert again.output == want.output and again.dd_log == want.dd_log
+    finally:
+        ctx.close()

@@ -71,6 +71,24 @@ def test_pipeline_rf00005_contralign_known_answers(oracle):
     pl.close()
 
 
+def test_pipeline_with_supplied_matching_rows(oracle):
+    """orc_pipeline_set_mp (the --align-aux path of the checker, align_model = 2): rows handed in equal rows computed"""
+    recs = oracle.fasta(os.path.join(G, "RF00005_0.fa"))[:6]
+    names, seqs = [n for n, _ in recs], [s for _, s in recs]
+    for model in (0, 1):
+        a = oracle.pipeline(names, seqs, oracle.params(fold_model=0, align_model=model))
+        a.phase1(); a.phase2()
+        b = oracle.pipeline(names, seqs, oracle.params(fold_model=0, align_model=2),
+                            mp=lambda x, y: oracle.align_calculate(seqs[x], seqs[y], 0.01, model))
+        b.phase1(); b.phase2()
+        assert a.output() == b.output() and a.output().count("\n") == 3 + 2 * len(seqs)
+        assert [list(v) for v in a.dd_log()] == [list(v) for v in b.dd_log()]
+        a.close(); b.close()
+    c = oracle.pipeline(names, seqs, oracle.params(fold_model=0, align_model=2))   # rows missing: refused, not computed
+    assert oracle.lib.orc_pipeline_phase1(c.h) != 0
+    c.close()
+
+
 def test_probcons_known_scalars(oracle):
     ka = known()
     seqs = [s for _, s in oracle.fasta(os.path.join(G, "RF00005_0.fa"))]

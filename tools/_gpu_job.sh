@@ -1,4 +1,6 @@
-timeout -k 10 600 python -m pytest tests/test_dd_gpu.py -x -q > gpurun_out/r2_dd_tests10.log 2>&1; tail -15 gpurun_out/r2_dd_tests10.log | cut -c1-300
-grep -q "Memory access fault" gpurun_out/r2_dd_tests10.log && exit 3
-python tools/time_stages.py 128 150 2>&1 | tail -3
-exit 0
+set -o pipefail
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_configs_gpu.py -x -q -s --durations=12 -k "fault_shape or failed_open or arena" > gpurun_out/r3_fault_tests.log 2>&1; rc=$?; tail -25 gpurun_out/r3_fault_tests.log
+[ $rc -ne 0 ] && exit $rc
+timeout -k 10 600 python -m pytest tests/test_dd_gpu.py -x -q --durations=8 > gpurun_out/r3_dd_tests.log 2>&1; rc=$?; tail -15 gpurun_out/r3_dd_tests.log
+exit $rc
