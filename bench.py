@@ -35,6 +35,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# Vector issue ceiling for arithmetic that must stay bit-exact with a non-contracting CPU build: plain (unpacked, unfused)
+# FP32 / integer lane-operations, 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz.  The 157.3 TFLOP/s spec figure counts a
+# packed FMA as four flops per lane slot; neither packing nor FMA contraction applies to an ordered float sum.
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+VALU_LANE_OPS = SIMDS * 16 * CLOCK_HZ
 BASE_N, BASE_L = 128, 150
 CONFIGS = {"c2": (32, 80), "c3": (128, 150), "c4": (256, 200), "c5": (512, 400)}  # BASELINE.json configs (N, L)
 
@@ -139,6 +144,91 @@ def cold_cli(names, seqs, contra):
     if r.returncode != 0:
         return {"error": r.stderr.strip()[-200:]}
     return {"wall_s": wall, "command": "dafs -s CONTRAfold --no-alifold%s FASTA" % (" -a CONTRAlign" if contra else ""), "stdout": r.stdout}
+
+
+def _pmc_file(kernel_name):
+    """the newest committed PMC summary (profiles/*_pmc.json, tools/pmc_summary.py) of this kernel instance and of these kernel sources"""
+    import glob
+    from dafs_amd import build
+    sha = build.source_sha16()  # a summary counts only for the kernel sources it measured
+    hit = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            pm = json.load(open(f))
+        except Exception:  # noqa: BLE001
+            continue
+        if isinstance(pm.get("kernel"), str) and pm["kernel"].startswith(kernel_name) and pm.get("kernel_source_sha16") == sha:
+            hit = (os.path.basename(f), pm)
+    return hit
+
+
+def _stage(ms, launches, alg_bytes=None, **more):
+    d = {"ms": round(ms, 4), "launches": launches}
+    if alg_bytes is not None:
+        d["algorithmic_bytes"] = float(alg_bytes)
+        d["achieved_GBps"] = alg_bytes / (ms * 1e-3) / 1e9 if ms else None
+        d["frac"] = d["achieved_GBps"] / HBM_PEAK_GBS if ms else None
+    d.update(more)
+    return d
+
+
+def stage_objects(ctx, seqs, lens, contra, rep, iso):
+    """bench line "stages": one entry per stage kernel of the whole run, each with its device time (HIP events around the
+    launches, summed; kernels on different streams overlap), SURVEY 8(d)'s algorithmic bytes, the fraction of the HBM peak,
+    and the bound that actually binds.  rep: Context.stage_report() of one whole run; iso: of one isolated node."""
+    n = len(seqs)
+    st = {}
+    L = lens.astype(np.float64)
+    if "k_contrafold" in rep:  # inside 3 tables + outside 3 tables + posterior = 28*S B per sequence, + F5 arrays 8(L+1)
+        ms, _, k = rep["k_contrafold"]
+        alg = float((28.0 * (L + 1) * (L + 2) / 2 + 8.0 * (L + 1)).sum())
+        st["k_contrafold"] = _stage(ms, k, alg, unit="28*S + 8(L+1) B per sequence, S=(L+1)(L+2)/2",
+                                    binding="latency: one workgroup per sequence, a span waits for its longest chain of log-sum-exps",
+                                    sequences=n, us_per_sequence_chain=ms * 1e3)
+    pp = ctx.mp(0)  # the un-relaxed store: what the transform reads
+    rowlen = [np.zeros((int(lens[z]), n), np.int64) for z in range(n)]  # rowlen[z][k, x] = entries of row k of mp[z][x]
+    for z in range(n):
+        rowlen[z][:, z] = 1  # identity (align.cpp:42-44)
+    nnz_total = 0
+    for p in range(len(pp)):
+        x, y = int(pp.pair_x[p]), int(pp.pair_y[p])
+        rowlen[x][:, y] = np.diff(pp.csr(p)[0].astype(np.int64))
+        rowlen[y][:, x] = np.diff(pp.csr(p, transposed=True)[0].astype(np.int64))
+        nnz_total += int(pp.nnz[p])
+    # relax_matching_probability (dafs.cpp:258-324): output pair (x, y) adds, over z and k, rowlen[z][k, x] * rowlen[z][k, y] products
+    addends = float(sum(((r.sum(axis=1) ** 2 - (r ** 2).sum(axis=1)).sum()) // 2 for r in rowlen))
+    lsum, lsq = float(L.sum()), float((L * L).sum())
+    pct_bytes = 8.0 * (n - 1) * (2.0 * nnz_total + lsum) + 4.0 * (lsum * lsum - lsq) / 2  # reads 2N CSR matrices per output pair + its dense tile
+    if "k_pct_rows" in rep:
+        ms, _, k = rep["k_pct_rows"]
+        lane_ops = 3.0 * addends  # multiply by w, multiply the two probabilities, add: none fusable (ordered float sum, no contraction)
+        st["k_pct_rows"] = _stage(ms, k, pct_bytes, unit="sum over output pairs of 8 B x entries of the 2N matrices read + 4*L1*L2 B written",
+                                  addends=addends, lane_ops=lane_ops, lane_ops_per_s=lane_ops / (ms * 1e-3) if ms else None,
+                                  valu_peak_lane_ops_per_s=VALU_LANE_OPS, frac_of_valu_peak=lane_ops / (ms * 1e-3) / VALU_LANE_OPS if ms else None,
+                                  binding="vector issue + gather latency (the addends are 3 plain lane-operations each; the stores stay cache-resident)")
+    for kname, per_cell in (("k_pairhmm3", 28.0), ("k_pairhmm5", 44.0)):
+        if kname in rep:
+            ms, _, k = rep[kname]
+            alg = per_cell * float((lsum + n) ** 2 - ((L + 1) ** 2).sum()) / 2  # sum over pairs of (L1+1)(L2+1)
+            st[kname + " (inside the whole run)"] = _stage(ms, k, alg, unit="%g*(L1+1)(L2+1) B per pair" % per_cell, binding="vector issue (see roofline.secondary)")
+    if "k_dd_solve" in rep:
+        ms, longest, k = rep["k_dd_solve"]
+        d = _stage(ms, k, None, longest_launch_ms=round(longest, 4),
+                   note="summed over the launches of both lanes of every round (they overlap); the guide tree serialises the nodes",
+                   binding="latency: one wavefront per subproblem, ~3 dependent DPs per iteration")
+        if iso and "k_dd_solve" in iso[0]:
+            ims, _, _ = iso[0]["k_dd_solve"]
+            its, l1, l2, ncbp = iso[1]
+            alg_it = 16.0 * (l1 * (l1 - 1) // 2 + l2 * (l2 - 1) // 2) + 13.0 * (l1 + 1) * (l2 + 1) + 64.0 * ncbp
+            d.update(isolated_node={"columns": [l1, l2], "iterations": its, "ms": round(ims, 4), "us_per_node_iteration": ims * 1e3 / its,
+                                    "algorithmic_bytes_per_iteration": alg_it, "achieved_GBps": alg_it * its / (ims * 1e-3) / 1e9,
+                                    "frac": alg_it * its / (ims * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "note": "one node of two single sequences alone on the device, forced to t_max iterations in one launch"})
+        st["k_dd_solve"] = d
+    for kname in ("k_pct_bp_rows", "k_pct_emit", "k_contrafold_posterior", "k_node_avg", "k_node_lists", "k_node_cbp_fill", "k_nussinov_single"):
+        if kname in rep:
+            st[kname] = _stage(rep[kname][0], rep[kname][2])
+    return st
 
 
 def main():
@@ -315,19 +405,23 @@ def main():
     alg_bytes = float(((44 if contra else 28) * (lens[px] + 1) * (lens[py] + 1)).sum())
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
-    # HBM traffic of the dominant kernel: from the committed rocprofv3 PMC passes (profiles/*_pmc.json,
-    # collected and corrected as MI355X_MICROARCH.md prescribes); only quoted when it is the same kernel.
+    # HBM traffic of the dominant kernel and its secondary (binding) limit: from the committed rocprofv3 PMC passes
+    # (profiles/*_pmc.json written by tools/pmc_summary.py, collected and corrected as MI355X_MICROARCH.md prescribes);
+    # only quoted when the newest such file is for this very kernel instance and workload, null otherwise.
     traffic = None
+    secondary = None
     kname = "k_pairhmm5" if contra else "k_pairhmm3"
-    kernel_name = "%s<G=%d,W=%d" % (kname, plan.group, plan.width)
-    try:
-        import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
-            pm = json.load(open(f))
-            if pm.get("kernel", "").startswith(kernel_name) and world == 1 and n_seq == BASE_N and args.length == BASE_L:
-                traffic = pm["hbm_bytes_per_launch"]
-    except Exception:  # noqa: BLE001
-        traffic = None
+    kernel_name = "%s<G=%d,W=%d>" % (kname, plan.group, plan.width)
+    pmf = _pmc_file(kernel_name) if (world == 1 and n_seq == cfg_n and args.length == cfg_l) else None
+    if pmf is not None and pmf[1].get("config") == args.config:
+        pm = pmf[1]
+        traffic = pm.get("hbm_bytes_per_launch")
+        valu = pm.get("per_launch", {}).get("SQ_INSTS_VALU")
+        if valu:
+            # a SIMD issues one VALU wave-instruction per 4 cycles at best (16 lanes per clock, 64-lane wavefronts)
+            secondary = {"bound": "valu-issue", "valu_wave_instructions_per_launch": valu,
+                         "frac": valu * 4.0 / (SIMDS * CLOCK_HZ * kern_ms * 1e-3),
+                         "formula": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel_ms)", "pmc_file": "profiles/" + pmf[0]}
 
     # ---- the timed call path against the oracle: a strided sample of the last launch's outputs, bit for bit ----
     verified = 0
@@ -355,6 +449,7 @@ def main():
 
     e2e = None
     dd_forced = None
+    stages = None
     if rank == 0 and world == 1 and not args.no_e2e:
         # BASELINE.json's second quantity: end-to-end wall-clock of the whole run (fold, pair posteriors,
         # consistency, tree, progressive DD, final structure) on the same set; not part of `value`.
@@ -394,6 +489,20 @@ def main():
                      "note": "k_dd_solve, all nodes forced to t_max=600 iterations; per node-iteration 2*16*L(L-1)/2 + 13*(L1+1)(L2+1) + 64*#cbp "
                              "algorithmic bytes, none of which crosses HBM for narrow nodes: the loop is latency-bound (one wavefront per "
                              "subproblem), the guide tree serialises the nodes"}
+        # per-stage device times of one more whole run (HIP events around every launch of the library: kept out of the
+        # timed run above), and of one node alone on the device
+        ctx.stage_timing(True)
+        pipeline.run(names, seqs, ctx=ctx, align_model=model, skip_uncoupled_folds=False)
+        rep = ctx.stage_report()
+        iso = None
+        try:
+            one = lambda i: (np.array([i], np.uint32), np.ones((1, int(lens[i])), np.uint8))
+            o = ctx.solve_nodes([one(0) + one(1)], capi.dd_params(force_iters=1))[0]
+            iso = (ctx.stage_report(), (int(o["iterations"]), int(lens[0]), int(lens[1]), int(o["ncbp"])))
+        except capi.DafsHipError:
+            iso = None
+        ctx.stage_timing(False)
+        stages = stage_objects(ctx, seqs, lens, contra, rep, iso)
         ctx.close()
 
     if rank == 0:
@@ -403,7 +512,7 @@ def main():
             "unit": "seq-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "N=%d L~%d synthetic random RNA (seed 12345), %d pairs%s" %
                                    (n_seq, args.length, total_pairs,
@@ -412,12 +521,13 @@ def main():
                        "kernel": "%s<G=%d,W=%d> x %d waves" % (kname, plan.group, plan.width, plan.nwaves)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes, "secondary": secondary},
             "cpu_baseline": cpu,
             "verified_pairs": verified,
         }
         if e2e is not None:
             out["end_to_end"] = e2e
+            out["stages"] = stages
         if dd_forced is not None:
             out["dd_forced_iterations"] = dd_forced
         print(json.dumps(out))

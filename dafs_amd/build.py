@@ -24,6 +24,16 @@ FLAGS += os.environ.get("DAFS_HIP_EXTRA_FLAGS", "").split()  # tuning experiment
 FILE_FLAGS = {"pairhmm3.hip": ["-fno-slp-vectorize"], "pairhmm5.hip": ["-fno-slp-vectorize"]}
 
 
+def source_sha16(names=("pairhmm3.hip", "pairhmm5.hip", "pair_sweeps.h", "pc_math.h", "contra_math.h")):
+    """sha256 (first 16 hex digits) of the pair kernels' sources: ties a committed PMC summary to the build it measured"""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(CSRC, n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 

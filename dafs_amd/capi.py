@@ -139,6 +139,12 @@ _update_basepairing = _sig("dafs_hip_update_basepairing", C.c_int, [C.c_void_p, 
 _consensus_structure = _sig("dafs_hip_consensus_structure", C.c_int,
                             [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                              C.POINTER(C.c_float), C.c_void_p])
+class StageTime(C.Structure):
+    _fields_ = [("kernel", C.c_char_p), ("ms", C.c_double), ("longest_ms", C.c_double), ("launches", C.c_uint32)]
+
+
+_stage_timing = _sig("dafs_hip_stage_timing", C.c_int, [C.c_void_p, C.c_int])
+_stage_report = _sig("dafs_hip_stage_report", C.c_int, [C.c_void_p, C.POINTER(StageTime), C.c_uint32, C.POINTER(C.c_uint32)])
 pairhmm_plan = _sig("dafs_hipk_pairhmm_plan", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PairhmmPlan)])
 pairhmm3_launch = _sig("dafs_hipk_pairhmm3_launch", C.c_int, [C.POINTER(Pairhmm3Args), C.POINTER(PairhmmPlan), C.c_void_p])
 pairhmm3_default_model = _sig("dafs_hip_pairhmm3_default_model", None, [C.POINTER(Pairhmm3Model)])
@@ -448,6 +454,17 @@ class Context:
         r, u, p = C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(_nodes_memory(self._h, C.byref(r), C.byref(u), C.byref(p)))
         return r.value, u.value, p.value
+
+    def stage_timing(self, enable=True):
+        """per-kernel device timings on / off (dafs_hip_stage_timing: HIP events around every launch of the library)"""
+        check(_stage_timing(self._h, 1 if enable else 0))
+
+    def stage_report(self):
+        """{kernel: (ms summed over its launches, longest launch ms, launches)} since the last report"""
+        buf = (StageTime * 32)()
+        n = C.c_uint32()
+        check(_stage_report(self._h, buf, 32, C.byref(n)))
+        return {buf[k].kernel.decode(): (buf[k].ms, buf[k].longest_ms, buf[k].launches) for k in range(min(n.value, 32))}
 
     def nodes_demotions(self):
         """split-mode nodes that lost their folding workgroups and went on in the one-workgroup form (since nodes_close)"""

@@ -95,12 +95,17 @@ static int consistency_parts(dafs_hip_ctx* c, float w_pct_a, float w_pct_s, int 
   mp_store_dev mpv = raw.view(c->d_len.ptr, n);
   int rc;
   // the row kernels gather {column, value} pairs: one interleaved copy of the input entries per transform
-  if ((rc = c->mp_ent2.reserve(raw.pool_used + 1))) return rc;
+  if ((rc = c->mp_ent2.reserve(raw.pool_used + 32))) return rc;  // + slack: k_pct_rows' unpredicated fetch reads up to 15 entries behind a row
   if ((rc = pct_interleave_launch(raw.col.ptr, raw.val.ptr, c->mp_ent2.ptr, raw.pool_used, c->stream))) return rc;
   mpv.ent2 = c->mp_ent2.ptr;
-  if ((rc = c->mp_ident2.reserve(max_len + 1))) return rc;
-  if ((rc = pct_ident_launch(c->mp_ident2.ptr, max_len + 1, c->stream))) return rc;
-  mpv.ident2 = c->mp_ident2.ptr;
+  {  // the identity matrix mp[x][x] as an ordinary CSR (entries {k, 1}, row pointers k): the row kernels treat it like any other
+    const uint32_t ni = max_len + 1 + 32;
+    if ((rc = c->mp_ident2.reserve((size_t)ni + ni / 2 + 2))) return rc;
+    uint32_t* ident_rp = (uint32_t*)(c->mp_ident2.ptr + ni);
+    if ((rc = pct_ident_launch(c->mp_ident2.ptr, ident_rp, ni, c->stream))) return rc;
+    mpv.ident2 = c->mp_ident2.ptr;
+    mpv.ident_rp = ident_rp;
+  }
   if ((rc = c->counters.reserve(4))) return rc;
   if (pair_end == 0) pair_end = all;
   if (pair_begin > pair_end || pair_end > all) return DAFS_HIP_EINVAL;

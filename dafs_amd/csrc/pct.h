@@ -56,7 +56,7 @@ struct pct_bp_args {
 
 // ent2[e] = {col[e], bits of val[e]} for e < n: the interleaved copy the row kernels gather from (mp_store_dev::ent2)
 int pct_interleave_launch(const uint32_t* col, const float* val, uint2* ent2, uint64_t n, hipStream_t st);
-int pct_ident_launch(uint2* ident2, uint32_t n, hipStream_t st);  // ident2[k] = {k, bits of 1.0f}
+int pct_ident_launch(uint2* ident2, uint32_t* ident_rp, uint32_t n, hipStream_t st);  // ident2[k] = {k, bits of 1.0f}, ident_rp[k] = k for k < n
 int pct_match_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint32_t count, hipStream_t st);
 int pct_bp_launch(pct_bp_args a, uint32_t max_len, hipStream_t st);
 // DAFS::relax_fourway_consistency (dafs.cpp:377-444) for the pairs [pair0, pair0 + count): same outputs as pct_match_launch

@@ -106,52 +106,155 @@ struct pct_round<16> {
   static __device__ __forceinline__ void apply(const uint2*, const pct_item&, int, uint32_t, const uint32_t (&)[16], const float (&)[16], float*, uint32_t) {}
 };
 
+// ---- round 3: the lean step ----------------------------------------------------------------------------------------
+// k_pct_rows is bound by vector issue (profiles/r02_j: 4.7 G VALU wave-instructions for 6.1 G addends) and the steps of
+// a round were 14 VALU instructions each: three broadcasts for the fetch, three for the apply, two compares with their
+// exec juggling, 64-bit address arithmetic.  Here a step is 8:
+//   fetch  address of entry t = item's byte address + 8 t as v_add_co / v_addc_co with the DPP broadcast folded into the
+//          operand (no v_mov_dpp); the load is NOT predicated -- lanes beyond the item's length read the entries that follow
+//          in the pool (the pools are padded by 16 entries), which costs no additional cache line
+//   apply  column = item length > t ? loaded column : the lane's own trash cell behind the row (one v_cmp_dpp + v_cndmask:
+//          no exec change, hence no exec-write -> DPP hazard stalls), two v_mul_f32_dpp (p_ik and w_z arrive through the DPP
+//          operand), address, LDS read, add, LDS write.
+// The DPP operands are inline assembly (the compiler does not fold v_mov_dpp row_newbcast into its users); "s_nop 1" in
+// front keeps the VALU-write -> DPP-read distance whatever the scheduler puts before the block.
+template <int Q>
+__device__ __forceinline__ float pct_mul_bc(float item, float x) {  // (item value of lane Q of the row) * x
+  float r;
+  asm("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(item), "v"(x), "n"(Q));
+  return r;
+}
+template <int Q>
+__device__ __forceinline__ uint32_t pct_sel_bc(uint32_t n_item, uint32_t t1, uint32_t yes, uint32_t no) {  // n of lane Q > t1 - 1 ? yes : no
+  // VOPC has no DPP form on gfx9, and the DPP operand of a subtraction is always the minuend (measured: v_subrev_dpp swaps
+  // before the DPP fetch, tools/scratch/dpp_test.hip): the borrow of n - (t + 1) says n <= t, i.e. the lane has no entry
+  uint32_t r, d;
+  asm("s_nop 1\n\tv_sub_co_u32_dpp %1, vcc, %2, %3 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\tv_cndmask_b32_e32 %0, %4, %5, vcc"
+      : "=v"(r), "=&v"(d) : "v"(n_item), "v"(t1), "v"(yes), "v"(no), "n"(Q) : "vcc");
+  return r;
+}
+template <int Q>
+__device__ __forceinline__ uint64_t pct_addr_bc(uint32_t lo_item, uint32_t hi_item, uint32_t t8, uint32_t zero) {  // address of lane Q + t8
+  uint32_t lo, hi;
+  asm("s_nop 1\n\tv_add_co_u32_dpp %0, vcc, %2, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_addc_co_u32_dpp %1, vcc, %3, %5, vcc row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+      : "=&v"(lo), "=v"(hi) : "v"(lo_item), "v"(hi_item), "v"(t8), "v"(zero), "n"(Q) : "vcc");
+  return ((uint64_t)hi << 32) | lo;
+}
+
+#ifndef PCT_TRASH_CELLS
+#define PCT_TRASH_CELLS 0
+#endif
+#ifndef PCT_FETCH_ALL
+#define PCT_FETCH_ALL 1  // 1: unpredicated fetch (two VALU instructions fewer per step; 0, predicated, measures the same: the kernel is issue-bound, not line-bound)
+#endif
+template <int Q>
+struct pct_step {
+  static __device__ __forceinline__ void fetch(const pct_item& it, uint32_t t8, uint32_t zero, uint32_t trash, pct_u2 (&cv)[16]) {
+#if PCT_FETCH_ALL
+    cv[Q] = *(const pct_gent*)pct_addr_bc<Q>(it.ptr_lo, it.ptr_hi, t8, zero);
+#else
+    // only the lanes that have an entry load: a 16-lane span behind a row's start crosses a 128-byte line far more often than
+    // the row's own ~6 entries do, and the kernel is bound by the line requests its gathers make
+    const uint64_t adr = pct_addr_bc<Q>(it.ptr_lo, it.ptr_hi, t8, zero);
+    pct_u2 e = {trash, 0u};
+    if (pct_sel_bc<Q>(it.n, (t8 >> 3) + 1u, 1u, 0u)) e = *(const pct_gent*)adr;
+    cv[Q] = e;
+#endif
+    pct_step<Q + 1>::fetch(it, t8, zero, trash, cv);
+  }
+  static __device__ __forceinline__ void apply(const pct_item& it, uint32_t t, uint32_t trash, const pct_u2 (&cv)[16], float* acc, uint32_t longq) {
+    const float v = pct_mul_bc<Q>(it.w, pct_mul_bc<Q>(it.pik, __uint_as_float(cv[Q].y)));  // (p_ik * p_kj) * w_z, dafs.cpp:300 / :308 / :316
+#if PCT_TRASH_CELLS
+    // every lane updates a cell, the ones without an entry their own trash cell: no exec change, but all 64 lanes go through
+    // the LDS, and the LDS is what binds (profiles/r03_a_pct_pmc.json: its pipe is busy 70 % of the kernel, 40 % of that conflicts)
+#if PCT_FETCH_ALL
+    const uint32_t col = pct_sel_bc<Q>(it.n, t + 1u, cv[Q].x, trash);
+#else
+    const uint32_t col = cv[Q].x;  // lanes without an entry carry {their trash cell, 0} from the fetch
+#endif
+    acc[col] += v;
+#else
+    if (pct_sel_bc<Q>(it.n, t + 1u, 1u, 0u)) acc[cv[Q].x] += v;  // only the lanes with an entry touch the LDS
+#endif
+    if (longq & (1u << Q)) {  // (scalar, rare) a b-row longer than the group: the rest of it, before the next item
+      const uint32_t n = row_bcast<Q>(it.n), lo = row_bcast<Q>(it.ptr_lo), hi = row_bcast<Q>(it.ptr_hi);
+      const float pik = row_bcastf<Q>(it.pik), w = row_bcastf<Q>(it.w);
+      const pct_gent* base = (const pct_gent*)(((uint64_t)hi << 32) | lo);
+      uint32_t nmax = n;
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, o));
+      for (uint32_t e0 = 16; e0 < nmax; e0 += 16) {
+        wave_lds_fence();
+        if (e0 + t < n) {
+          const pct_u2 e = base[e0 + t];
+          acc[e.x] += pik * __uint_as_float(e.y) * w;
+        }
+      }
+    }
+    wave_lds_fence();
+    pct_step<Q + 1>::apply(it, t, trash, cv, acc, longq);
+  }
+};
+template <>
+struct pct_step<16> {
+  static __device__ __forceinline__ void fetch(const pct_item&, uint32_t, uint32_t, uint32_t, pct_u2 (&)[16]) {}
+  static __device__ __forceinline__ void apply(const pct_item&, uint32_t, uint32_t, const pct_u2 (&)[16], float*, uint32_t) {}
+};
+
+// LDS of one group (= one output row), in words: 16 trash cells behind the accumulator row, then the chunk's bookkeeping
+// (item address bases 16 x 2, exclusive item offsets 20; 16 spare).  row_cap = 28 (mod 32) makes the stride 16 (mod 32):
+// the two rows a 32-lane half updates sit sixteen banks apart (see pct_match_launch).
+#define PCT_TRASH 16
+#define PCT_BOOK_WORDS (16 * 2 + 20 + 16)
+__host__ __device__ static inline size_t pct_group_words(uint32_t row_cap) { return (size_t)row_cap + PCT_TRASH + PCT_BOOK_WORDS; }
+
 __global__ __launch_bounds__(256) void k_pct_rows(pct_match_args a, uint32_t pair0, uint32_t row_cap) {
   extern __shared__ unsigned char s_raw[];
   const uint32_t N = a.in.nseq;
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
-  const int t = (int)(tid & 15), gw = (int)(tid >> 4);
-  // workgroup tables, per z: row-pointer base and entry base of mp[x][z] and of mp[z][y], and w_z
+  const uint32_t t = tid & 15u;
+  const int gw = (int)(tid >> 4);
+  // workgroup tables, per z: ADDRESSES of the row pointers and of the entries of mp[x][z] (a-side) and of mp[z][y] (b-side),
+  // and w_z.  The identity matrices mp[x][x] and mp[y][y] (align.cpp:42-44) are ordinary CSRs here (ident_rp / ident2), so
+  // that no step of the row loop knows about them.
   uint64_t* a_rp = (uint64_t*)s_raw;
   uint64_t* a_ent = a_rp + N;
   uint64_t* b_rp = a_ent + N;
   uint64_t* b_ent = b_rp + N;
   float* wz = (float*)(b_ent + N);
-  // per group (= per output row): a-row bookkeeping of the current chunk of 16 sequences, then the accumulator row
-  unsigned char* gbase = (unsigned char*)(wz + ((N + 1) & ~1u)) + (size_t)gw * ((size_t)row_cap * 4 + 16 * 8 + 20 * 4 + 16 * 4);
-  uint64_t* zaent = (uint64_t*)gbase;
-  uint32_t* zoff = (uint32_t*)(zaent + 16);
-  uint32_t* zid = zoff + 20;
-  float* acc = (float*)(zid + 16);
+  // per group (= per output row): the accumulator row, the lanes' trash cells, the a-row bookkeeping of the current chunk
+  float* acc = wz + ((N + 1) & ~1u) + (size_t)gw * pct_group_words(row_cap);
+  uint64_t* zabase = (uint64_t*)(acc + row_cap + PCT_TRASH);  // per z-lane: address of item tl of the chunk = zabase + 8 tl
+  uint32_t* zoff = (uint32_t*)(zabase + 16);                   // exclusive item offsets of the z-lanes (zoff[16] = items of the chunk)
 
   const uint32_t p = pair0 + blockIdx.x;
   const uint32_t x = a.pair_x[p], y = a.pair_y[p];
   const uint32_t L1 = a.in.len[x], L2 = a.in.len[y];
   const uint32_t row0 = blockIdx.y * PCT_ROWS_PER_WG;
   if (row0 >= L1) return;
-  // dafs.cpp:280-288 and the bases of the two sparse matrices every z contributes
+  // dafs.cpp:280-288 and the two sparse matrices every z contributes
   for (uint32_t z = tid; z < N; z += nt) {
     float w = a.sim[(size_t)z * N + x] * a.sim[(size_t)z * N + y];
     if (a.w_pct < 0.0) w *= 1.0 / N;
     else if (z == x || z == y) w *= (1.0 - a.w_pct) / 2;
     else w *= a.w_pct / (N - 2);
     wz[z] = w;
-    // mp[x][z] (for z == y this is mp[x][y] itself; for z == x unused) and mp[z][y] (for z == x: mp[x][y]; z == y unused)
-    const uint32_t za = (z == x) ? y : z;
-    {
-      const uint32_t lo = x < za ? x : za, hi = x < za ? za : x;
+    if (z == x) { a_rp[z] = (uint64_t)a.in.ident_rp; a_ent[z] = (uint64_t)a.in.ident2; }  // mp[x][x]
+    else {
+      const uint32_t lo = x < z ? x : z, hi = x < z ? z : x;
       const uint32_t tk = a.in.task_of_pair[pair_id(lo, hi, N)];
-      const bool fwd = x < za;
-      a_rp[z] = a.in.rp_off[tk] + (fwd ? 0 : a.in.len[lo] + 1);
-      a_ent[z] = a.in.pair_off[tk] + (fwd ? 0 : a.in.pair_nnz[tk]);
+      const bool fwd = x < z;
+      a_rp[z] = (uint64_t)(a.in.rowptr_pool + (a.in.rp_off[tk] + (fwd ? 0 : a.in.len[lo] + 1)));
+      a_ent[z] = (uint64_t)(a.in.ent2 + (a.in.pair_off[tk] + (fwd ? 0 : a.in.pair_nnz[tk])));
     }
-    const uint32_t zb = (z == y) ? x : z;
-    {
-      const uint32_t lo = zb < y ? zb : y, hi = zb < y ? y : zb;
+    if (z == y) { b_rp[z] = (uint64_t)a.in.ident_rp; b_ent[z] = (uint64_t)a.in.ident2; }  // mp[y][y]
+    else {
+      const uint32_t lo = z < y ? z : y, hi = z < y ? y : z;
       const uint32_t tk = a.in.task_of_pair[pair_id(lo, hi, N)];
-      const bool fwd = zb < y;
-      b_rp[z] = a.in.rp_off[tk] + (fwd ? 0 : a.in.len[lo] + 1);
-      b_ent[z] = a.in.pair_off[tk] + (fwd ? 0 : a.in.pair_nnz[tk]);
+      const bool fwd = z < y;
+      b_rp[z] = (uint64_t)(a.in.rowptr_pool + (a.in.rp_off[tk] + (fwd ? 0 : a.in.len[lo] + 1)));
+      b_ent[z] = (uint64_t)(a.in.ent2 + (a.in.pair_off[tk] + (fwd ? 0 : a.in.pair_nnz[tk])));
     }
   }
   __syncthreads();
@@ -164,78 +267,83 @@ __global__ __launch_bounds__(256) void k_pct_rows(pct_match_args a, uint32_t pai
 
   const uint32_t i = row0 + (uint32_t)gw;
   const bool rowact = i < L1;
-  for (uint32_t j = (uint32_t)t; j < L2; j += PCT_G) acc[j] = 0.0f;
+  const uint32_t t8 = t * 8u, zero = 0u, trash = row_cap + t;
+  for (uint32_t j = t; j < L2; j += PCT_G) acc[j] = 0.0f;
+
+  // One item = one (z, k) of the row: lane tl - w0 of the group prepares item tl of the chunk -- the a-entry (k, p_ik), then
+  // the row pointers of mp[z][y][k] -- in three branch-free pieces, so that round r + 1's a-entry load is in flight while
+  // round r's entries are fetched, and its row-pointer load while round r is applied.  Lanes without an item prepare item 0
+  // of the chunk again (valid addresses) and get length 0.
+  struct half_item { uint32_t z; bool have; pct_u2 ak; };             // ak: the a-entry {k, p_ik}
+  struct item_loads { uint32_t z; float pik; bool have; pct_u2 rp; }; // rp: {first entry, end} of the b-row
   for (uint32_t zc = 0; zc < N; zc += PCT_G) {
+    auto item_a = [&](uint32_t tl, uint32_t T1) {
+      half_item h;
+      h.have = tl < T1;
+      const uint32_t tc = h.have ? tl : 0u;
+      uint32_t zz = (tc >= zoff[8]) ? 8u : 0u;  // the last z-lane whose first item is not behind tl (empty rows share their offset with the next)
+      zz += (tc >= zoff[zz + 4]) ? 4u : 0u;
+      zz += (tc >= zoff[zz + 2]) ? 2u : 0u;
+      zz += (tc >= zoff[zz + 1]) ? 1u : 0u;
+      h.z = min(zc + zz, N - 1);
+      h.ak = *(const pct_gent*)(zabase[zz] + (uint64_t)tc * 8u);
+      return h;
+    };
+    auto item_b_loads = [&](const half_item& h) {
+      item_loads q;
+      q.z = h.z; q.have = h.have; q.pik = __uint_as_float(h.ak.y);
+      q.rp = *(const pct_gent*)(b_rp[h.z] + (uint64_t)h.ak.x * 4u);    // 4-byte aligned 8-byte load: row pointers k and k + 1
+      return q;
+    };
+    auto item_b_finish = [&](const item_loads& q) {
+      pct_item it;
+      const uint64_t adr = b_ent[q.z] + (uint64_t)q.rp.x * 8u;
+      it.n = q.have ? q.rp.y - q.rp.x : 0u;
+      it.pik = q.pik;
+      it.w = wz[q.z];
+      it.ptr_lo = (uint32_t)adr; it.ptr_hi = (uint32_t)(adr >> 32);
+      return it;
+    };
     // ---- a-rows of the chunk, one lane per z
-    uint32_t na = 0;
+    uint32_t na = 0, beg = 0;
+    uint64_t entbase = (uint64_t)a.in.ident2;
     {
-      const uint32_t z = zc + (uint32_t)t;
-      uint32_t id = z;
-      uint64_t ent = 0;
+      const uint32_t z = zc + t;
       if (rowact && z < N) {
-        if (z == x) { na = 1; id |= 0x80000000u; }  // mp[x][x][i] = {(i, 1)}
-        else {
-          const uint32_t beg = a.in.rowptr_pool[a_rp[z] + i], end = a.in.rowptr_pool[a_rp[z] + i + 1];
-          na = end - beg;
-          ent = a_ent[z] + beg;
-          if (z == y) id |= 0x40000000u;             // mp[y][y][k] = {(k, 1)}
-        }
+        const pct_u2 be = *(const pct_gent*)(a_rp[z] + (uint64_t)i * 4u);
+        beg = be.x; na = be.y - be.x;
+        entbase = a_ent[z];
       }
-      zaent[t] = ent;
-      zid[t] = id;
     }
     uint32_t incl = na;
 #pragma unroll
     for (int o = 1; o < PCT_G; o <<= 1) {
       const uint32_t up = __shfl_up(incl, o, PCT_G);
-      if (t >= o) incl += up;
+      if ((int)t >= o) incl += up;
     }
     zoff[t + 1] = incl;
     if (t == 0) zoff[0] = 0;
+    zabase[t] = entbase + ((uint64_t)beg - (uint64_t)(incl - na)) * 8u;  // so that item tl of the chunk is at zabase + 8 tl
     const uint32_t T1 = row_bcast<15>(incl);  // items of this row in this chunk
     uint32_t T1max = T1;
 #pragma unroll
     for (int o = 16; o < 64; o <<= 1) T1max = max(T1max, (uint32_t)__shfl_xor((int)T1max, o));
     T1max = __builtin_amdgcn_readfirstlane(T1max);
     wave_lds_fence();
-    // ---- rounds of 16 items per row
+    // ---- rounds of 16 items per row, the next round's items prepared while this round runs
+    pct_item it = item_b_finish(item_b_loads(item_a(t, T1)));
     for (uint32_t w0 = 0; w0 < T1max; w0 += PCT_G) {
-      const uint32_t tl = w0 + (uint32_t)t;
-      pct_item it;
-      it.ptr_lo = 0; it.ptr_hi = 0; it.n = 0; it.pik = 0.0f; it.w = 0.0f;
-      uint32_t k = 0, id = 0;
-      const bool have = tl < T1;
-      if (have) {
-        uint32_t zz = 0;
-#pragma unroll
-        for (int q = 1; q < PCT_G; ++q) zz += (tl >= zoff[q]) ? 1u : 0u;
-        id = zid[zz];
-        k = i;
-        it.pik = 1.0f;
-        if (!(id & 0x80000000u)) { const uint2 cv = a.in.ent2[zaent[zz] + (tl - zoff[zz])]; k = cv.x; it.pik = __uint_as_float(cv.y); }
-      }
-      if (have) {
-        const uint32_t z = id & 0x3FFFFFFFu;
-        it.w = wz[z];
-        if (id & 0x40000000u) {
-          const uint64_t adr = (uint64_t)(a.in.ident2 + k);
-          it.n = 1; it.ptr_lo = (uint32_t)adr; it.ptr_hi = (uint32_t)(adr >> 32);
-        } else {
-          const uint32_t bb = a.in.rowptr_pool[b_rp[z] + k], be = a.in.rowptr_pool[b_rp[z] + k + 1];
-          const uint64_t ptr = b_ent[z] + bb;
-          const uint64_t adr = (uint64_t)(a.in.ent2 + ptr);
-          it.n = be - bb; it.ptr_lo = (uint32_t)adr; it.ptr_hi = (uint32_t)(adr >> 32);
-        }
-      }
-      uint32_t jc[16];
-      float pv[16];
-      pct_round<0>::fetch(a.in.ent2, it, t, jc, pv);
-      pct_round<0>::apply(a.in.ent2, it, t, 0u, jc, pv, acc, pct_long_slots(it.n));
+      const half_item hn = item_a(w0 + PCT_G + t, T1);   // a-entry load of the next round: in flight during this round's fetch
+      pct_u2 cv[16];
+      pct_step<0>::fetch(it, t8, zero, trash, cv);
+      const item_loads qn = item_b_loads(hn);            // its row-pointer load: in flight during this round's apply
+      pct_step<0>::apply(it, t, trash, cv, acc, pct_long_slots(it.n));
+      it = item_b_finish(qn);
     }
     wave_lds_fence();
   }
   if (rowact)
-    for (uint32_t j = (uint32_t)t; j < L2; j += PCT_G) tile[(size_t)i * L2 + j] = acc[j];
+    for (uint32_t j = t; j < L2; j += PCT_G) tile[(size_t)i * L2 + j] = acc[j];
 }
 
 __global__ __launch_bounds__(256) void k_pct_emit(pct_match_args a, uint32_t pair0) {
@@ -596,6 +704,10 @@ static const size_t kPctLdsBytes = 150 * 1024;  // leave room for the static LDS
 size_t pct_rows_lds_bytes(uint32_t nseq, uint32_t row_cap) {
   return (size_t)nseq * 32 + (((size_t)nseq + 1) & ~(size_t)1) * 4 + (size_t)PCT_ROWS_PER_WG * ((size_t)row_cap * 4 + 16 * 8 + 20 * 4 + 16 * 4) + 64;
 }
+// k_pct_rows (round 3 layout: trash cells behind every accumulator row)
+size_t pct_rows2_lds_bytes(uint32_t nseq, uint32_t row_cap) {
+  return (size_t)nseq * 32 + (((size_t)nseq + 1) & ~(size_t)1) * 4 + (size_t)PCT_ROWS_PER_WG * pct_group_words(row_cap) * 4 + 64;
+}
 
 // pairs [pair0, pair0 + count) whose tiles (a.tile, a.tile_off, a.sum_w) have been laid out by the caller
 // ---------------------------------------------------------------------------------------------
@@ -670,13 +782,13 @@ __global__ __launch_bounds__(256) void k_mp_interleave(const uint32_t* __restric
     ent2[e] = make_uint2(col[e], __float_as_uint(val[e]));
 }
 
-__global__ __launch_bounds__(256) void k_mp_ident(uint2* __restrict__ ident2, uint32_t n) {
+__global__ __launch_bounds__(256) void k_mp_ident(uint2* __restrict__ ident2, uint32_t* __restrict__ ident_rp, uint32_t n) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) ident2[k] = make_uint2(k, 0x3F800000u);
+  if (k < n) { ident2[k] = make_uint2(k, 0x3F800000u); ident_rp[k] = k; }
 }
-int pct_ident_launch(uint2* ident2, uint32_t n, hipStream_t st) {
+int pct_ident_launch(uint2* ident2, uint32_t* ident_rp, uint32_t n, hipStream_t st) {
   if (!n) return DAFS_HIP_OK;
-  hipLaunchKernelGGL(k_mp_ident, dim3((n + 255) / 256), dim3(256), 0, st, ident2, n);
+  hipLaunchKernelGGL(k_mp_ident, dim3((n + 255) / 256), dim3(256), 0, st, ident2, ident_rp, n);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 
@@ -698,12 +810,12 @@ int pct_fourway_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint3
 
 int pct_match_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint32_t count, hipStream_t st) {
   if (!count) return DAFS_HIP_OK;
-  // The four rows a wavefront accumulates sit row_cap + 68 words apart in LDS, and the two rows of a 32-lane half
-  // add into nearly the same 16-column window (rows i and i+1 of one pair): row_cap = 12 (mod 32) puts the second row
-  // sixteen banks away from the first (a multiple of 16, as before, put it four banks away: two lanes per bank on
-  // almost every update -- 1.9 G conflict cycles per 2.3 G LDS instructions at N = 128).
-  const uint32_t row_cap = max_len + ((12u - max_len) & 31u);
-  const size_t lds = pct_rows_lds_bytes(a.in.nseq, row_cap);
+  // The four rows a wavefront accumulates sit pct_group_words(row_cap) = row_cap + 84 words apart in LDS, and the two rows
+  // of a 32-lane half add into nearly the same 16-column window (rows i and i+1 of one pair): row_cap = 28 (mod 32) puts the
+  // second row sixteen banks away from the first (four banks away: two lanes per bank on almost every update -- 1.9 G
+  // conflict cycles per 2.3 G LDS instructions at N = 128).
+  const uint32_t row_cap = max_len + ((28u - max_len) & 31u);
+  const size_t lds = pct_rows2_lds_bytes(a.in.nseq, row_cap);
   if (lds > kPctLdsBytes) return DAFS_HIP_ETOOLONG;
   a.max_len = max_len;
   static bool attr[16] = {false};

@@ -17,6 +17,7 @@ struct mp_store_dev {
   const uint2* ent2;             // optional: the same entries interleaved, {col, bits of val} (the consistency kernels' gathers
                                  // fetch one line per row instead of two; built per transform by pct_interleave_launch)
   const uint2* ident2;           // optional, with ent2: ident2[k] = {k, bits of 1.0f}, the row k of an identity matrix mp[x][x]
+  const uint32_t* ident_rp;      // optional, with ident2: ident_rp[k] = k, the row pointers of that identity matrix
   const uint64_t* pair_off;      // per task: first entry of mp[a][b]; mp[b][a] follows after nnz entries
   const uint32_t* pair_nnz;      // per task
   const uint64_t* rp_off;        // per task: first row pointer (len[a]+1 of them, then len[b]+1)

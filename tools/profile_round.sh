@@ -5,10 +5,10 @@
 tag=${1:-rXX}
 root=$(pwd)
 out=$root/gpurun_out
-python3 bench.py > $out/${tag}_bench_line.json 2> $out/${tag}_bench_line.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench_line.json 2> $out/${tag}_bench_line.err
 tail -c 400 $out/${tag}_bench_line.json; echo
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${tag}_pc -o p -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu --no-e2e > $out/prof_${tag}_pc.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${tag}_pc -o p -- python3 $root/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-e2e > $out/prof_${tag}_pc.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${tag}_e2e -o p -- python3 $root/tools/time_stages.py 128 150 > $out/prof_${tag}_e2e.log 2>&1
 cd $root
 cp $out/prof_${tag}_pc/p_kernel_stats.csv $out/${tag}_pairhmm3_kernel_stats.csv
