@@ -1,6 +1,7 @@
 // dafs_amd/csrc/capi_pct.cpp -- L1: base-pairing store upload/fetch and the two probabilistic
 // consistency transforms (reference src/dafs.cpp:258-375, called at :1822-1827).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -75,6 +76,37 @@ extern "C" int dafs_hip_bp_fetch(dafs_hip_ctx* c, int relaxed, uint32_t* rowptr,
   }
   return DAFS_HIP_OK;
 }
+
+namespace dafs {
+void pct_task_order(const uint32_t* pair_x, const uint32_t* pair_y, const uint32_t* len, uint32_t nseq, uint64_t p0, uint32_t count,
+                    std::vector<uint2>& out) {
+  // pairs of the launch bucketed by y (stable: x ascending within a bucket)
+  std::vector<uint32_t> first(nseq + 1, 0), by_y(count);
+  for (uint32_t k = 0; k < count; ++k) ++first[pair_y[p0 + k] + 1];
+  for (uint32_t y = 0; y < nseq; ++y) first[y + 1] += first[y];
+  {
+    std::vector<uint32_t> cur(first.begin(), first.end() - 1);
+    for (uint32_t k = 0; k < count; ++k) by_y[cur[pair_y[p0 + k]]++] = k;
+  }
+  std::vector<uint2> tasks;
+  tasks.reserve((size_t)count * 12);
+  for (uint32_t y = 0; y < nseq; ++y) {
+    uint32_t rbmax = 0;
+    for (uint32_t q = first[y]; q < first[y + 1]; ++q) rbmax = std::max(rbmax, (len[pair_x[p0 + by_y[q]]] + 15u) / 16u);
+    for (uint32_t rb = 0; rb < rbmax; ++rb)
+      for (uint32_t q = first[y]; q < first[y + 1]; ++q) {
+        const uint32_t k = by_y[q];
+        if (rb * 16u < len[pair_x[p0 + k]]) tasks.push_back(make_uint2(k, rb));
+      }
+  }
+  const size_t total = tasks.size(), per = (total + 7) / 8;
+  out.assign(per * 8, make_uint2(0xFFFFFFFFu, 0u));
+  for (size_t b = 0; b < per * 8; ++b) {  // workgroup b runs on XCD b mod 8: each XCD gets one contiguous range of the sorted tasks
+    const size_t src = (b % 8) * per + b / 8;
+    if (src < total) out[b] = tasks[src];
+  }
+}
+}  // namespace dafs
 
 // relax_basepairing_probability then relax_matching_probability, both from the un-relaxed
 // stores (dafs.cpp:1822-1827).  A weight of 0 skips that transform, as the reference does.
@@ -210,6 +242,16 @@ static int consistency_parts(dafs_hip_ctx* c, float w_pct_a, float w_pct_s, int 
         if (hip_check(hipMemcpyAsync(c->work.ptr, toff.data(), cnt * 8, hipMemcpyHostToDevice, c->stream))) return DAFS_HIP_ELAUNCH;
         if (hip_check(hipStreamSynchronize(c->stream))) return DAFS_HIP_ELAUNCH;  // toff dies at the end of the scope
         a.tile = c->scratch.ptr; a.tile_off = (const uint64_t*)c->work.ptr; a.sum_w = (float*)c->work2.ptr;
+        a.wg_task = nullptr; a.wg_tasks = 0;
+        // DAFS_HIP_PCT_YORDER=1 (tuning aid): workgroups ordered by (y, row block, x) and dealt to the XCDs in contiguous ranges.
+        // Measured slower than the plain 2-D grid (N=128: 13.3 against 12.8 ms for the stage, N=256: 135 against 120): the
+        // gathers are not what binds the kernel, so the default stays the 2-D grid.
+        if (!fourway && getenv("DAFS_HIP_PCT_YORDER")) {
+          std::vector<uint2> order;
+          pct_task_order(raw.pair_x.data(), raw.pair_y.data(), c->len.data(), n, p0, (uint32_t)cnt, order);
+          if ((rc = c->pct_tasks.upload(order.data(), order.size(), c->stream))) return rc;  // synchronises
+          a.wg_task = c->pct_tasks.ptr; a.wg_tasks = (uint32_t)order.size();
+        }
         if ((rc = fourway ? pct_fourway_launch(a, max_len, (uint32_t)p0, (uint32_t)cnt, c->stream)
                           : pct_match_launch(a, max_len, (uint32_t)p0, (uint32_t)cnt, c->stream))) return rc;
         p0 = p1;

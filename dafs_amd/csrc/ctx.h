@@ -119,6 +119,7 @@ struct dafs_hip_ctx {
   dafs::dev_buf<float> d_sim;
   dafs::dev_buf<uint32_t> d_pair_x, d_pair_y;
   dafs::dev_buf<uint2> mp_ident2;  // rows of an identity matrix, {k, 1.0f}
+  dafs::dev_buf<uint2> pct_tasks;  // workgroup order of k_pct_rows (pct_task_order)
   dafs::dev_buf<uint2> mp_ent2;  // interleaved copy of the un-relaxed matching store's entries (consistency transforms)
   // CONTRAfold workspaces
   bool cf_params_ready = false;
@@ -241,7 +242,7 @@ struct dafs_hip_ctx {
 
   void free_all() {
     codes.release(); d_len.release(); d_seq_rp_off.release(); tasks.release(); scratch.release(); task_sim.release();
-    counters.release(); d_sim.release(); d_pair_x.release(); d_pair_y.release(); mp_ent2.release(); mp_ident2.release(); work.release(); work2.release(); d_nodes.release(); d_paused.release(); d_nodes2.release(); d_paused2.release(); d_tref.release(); for (int k = 0; k < 2; ++k) { d_pack_off[k].release(); d_pack[k].release(); } dd_release();
+    counters.release(); d_sim.release(); d_pair_x.release(); d_pair_y.release(); mp_ent2.release(); mp_ident2.release(); pct_tasks.release(); work.release(); work2.release(); d_nodes.release(); d_paused.release(); d_nodes2.release(); d_paused2.release(); d_tref.release(); for (int k = 0; k < 2; ++k) { d_pack_off[k].release(); d_pack[k].release(); } dd_release();
     for (int k = 0; k < 2; ++k) { if (h_paused[k]) (void)hipHostFree(h_paused[k]); h_paused[k] = nullptr; h_paused_cap[k] = 0; }
     d_cf_params.release(); cf_seqs.release(); cf_codes.release(); cf_iws.release(); cf_cons.release(); cf_fws.release(); cf_post.release(); cf_logz.release();
     for (int k = 0; k < 2; ++k) { mp[k].release(); bp[k].release(); }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 #include "sparse_view.h"
 
 namespace dafs {
@@ -28,6 +29,10 @@ struct pct_match_args {
   const uint64_t* tile_off;
   float* sum_w;           // per pair of the launch: sum of the weights w_z (written by the row kernel)
   uint32_t max_len;       // filled by the launcher
+  // optional (k_pct_rows): the launch's workgroups as a 1-D list of {pair index within the launch, block of 16 rows}; null =
+  // a 2-D grid (pair, row block).  pct_task_order builds it.
+  const uint2* wg_task;
+  uint32_t wg_tasks;
   // four-way transform only (pct_fourway_launch): the un-relaxed base-pairing store and the weight -f
   bp_store_dev bp;
   float w_f;
@@ -53,6 +58,13 @@ struct pct_bp_args {
   float* sum_w;
   uint32_t max_len;
 };
+
+// Workgroup order of k_pct_rows for the pairs [p0, p0 + count) of a launch (host): the tasks (pair, block of 16 rows) sorted by
+// (y, row block, x) -- every workgroup of such a run gathers the same b-rows mp[z][y][k ~ row block], only the a-side differs --
+// and dealt to the XCDs in contiguous ranges (workgroup b runs on XCD b mod 8), so that what an XCD's L2 (4 MB) serves at a
+// time is one or two (y, row block) groups instead of a slice of every matrix of the store.  Padding entries hold x = ~0.
+void pct_task_order(const uint32_t* pair_x, const uint32_t* pair_y, const uint32_t* len, uint32_t nseq, uint64_t p0, uint32_t count,
+                    std::vector<uint2>& out);
 
 // ent2[e] = {col[e], bits of val[e]} for e < n: the interleaved copy the row kernels gather from (mp_store_dev::ent2)
 int pct_interleave_launch(const uint32_t* col, const float* val, uint2* ent2, uint64_t n, hipStream_t st);

@@ -228,10 +228,18 @@ __global__ __launch_bounds__(256) void k_pct_rows(pct_match_args a, uint32_t pai
   uint64_t* zabase = (uint64_t*)(acc + row_cap + PCT_TRASH);  // per z-lane: address of item tl of the chunk = zabase + 8 tl
   uint32_t* zoff = (uint32_t*)(zabase + 16);                   // exclusive item offsets of the z-lanes (zoff[16] = items of the chunk)
 
-  const uint32_t p = pair0 + blockIdx.x;
+  // which (pair, block of 16 rows) this workgroup takes: from the launch's task table (pct_match_launch: ordered so that the
+  // workgroups an XCD runs at the same time share y and the row block, i.e. the b-rows they gather), or from the 2-D grid
+  uint32_t pl = blockIdx.x, rb = blockIdx.y;
+  if (a.wg_task) {
+    const uint2 tk = a.wg_task[blockIdx.x];
+    pl = tk.x; rb = tk.y;
+    if (pl == 0xFFFFFFFFu) return;  // padding of the XCD interleave
+  }
+  const uint32_t p = pair0 + pl;
   const uint32_t x = a.pair_x[p], y = a.pair_y[p];
   const uint32_t L1 = a.in.len[x], L2 = a.in.len[y];
-  const uint32_t row0 = blockIdx.y * PCT_ROWS_PER_WG;
+  const uint32_t row0 = rb * PCT_ROWS_PER_WG;
   if (row0 >= L1) return;
   // dafs.cpp:280-288 and the two sparse matrices every z contributes
   for (uint32_t z = tid; z < N; z += nt) {
@@ -258,12 +266,12 @@ __global__ __launch_bounds__(256) void k_pct_rows(pct_match_args a, uint32_t pai
     }
   }
   __syncthreads();
-  if (blockIdx.y == 0 && tid == 0) {
+  if (rb == 0 && tid == 0) {
     float sw = 0.0f;
     for (uint32_t z = 0; z < N; ++z) sw += wz[z];
-    a.sum_w[blockIdx.x] = sw;
+    a.sum_w[pl] = sw;
   }
-  float* tile = a.tile + a.tile_off[blockIdx.x];
+  float* tile = a.tile + a.tile_off[pl];
 
   const uint32_t i = row0 + (uint32_t)gw;
   const bool rowact = i < L1;
@@ -820,7 +828,11 @@ int pct_match_launch(pct_match_args a, uint32_t max_len, uint32_t pair0, uint32_
   a.max_len = max_len;
   static bool attr[16] = {false};
   if (!lds_optin_once((const void*)k_pct_rows, (int)kPctLdsBytes, attr)) return DAFS_HIP_ELAUNCH;
-  STAGE_LAUNCH(ST_PCT_ROWS, st) hipLaunchKernelGGL(k_pct_rows, dim3(count, (max_len + PCT_ROWS_PER_WG - 1) / PCT_ROWS_PER_WG), dim3(256), lds, st, a, pair0, row_cap);
+  if (a.wg_task) {
+    STAGE_LAUNCH(ST_PCT_ROWS, st) hipLaunchKernelGGL(k_pct_rows, dim3(a.wg_tasks), dim3(256), lds, st, a, pair0, row_cap);
+  } else {
+    STAGE_LAUNCH(ST_PCT_ROWS, st) hipLaunchKernelGGL(k_pct_rows, dim3(count, (max_len + PCT_ROWS_PER_WG - 1) / PCT_ROWS_PER_WG), dim3(256), lds, st, a, pair0, row_cap);
+  }
   if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
   STAGE_LAUNCH(ST_PCT_EMIT, st) hipLaunchKernelGGL(k_pct_emit, dim3(count), dim3(256), (size_t)2 * (max_len + 2) * 4, st, a, pair0);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;

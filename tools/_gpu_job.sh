@@ -5,4 +5,5 @@ timeout -k 10 300 python -m pytest tests/test_pct_gpu.py -x -q > gpurun_out/r3_p
 python tools/scratch/pct_time.py 128 150 2>&1 | grep -v amdgpu.ids | tail -1
 python tools/scratch/pct_time.py 256 200 2>&1 | grep -v amdgpu.ids | tail -1
 python tools/scratch/pct_time.py 128 150 family 2>&1 | grep -v amdgpu.ids | tail -1
+DAFS_HIP_PCT_GRID2D=1 python tools/scratch/pct_time.py 128 150 2>&1 | grep -v amdgpu.ids | tail -1
 exit $rc
