@@ -447,6 +447,34 @@ def main():
                 raise SystemExit("bench: pair (%d, %d) of the timed launch differs from the oracle" % (x, y))
             verified += 1
 
+    # ---- the exchange (RCCL all-gather of the packed slabs) against what this rank produced: every pair of this rank's shard
+    # must come back from the gathered slab exactly as the kernel wrote it (with one rank and DAFS_BENCH_FORCE_EXCHANGE=1 this
+    # is the whole set: the test that runs the nccl = RCCL backend on a one-GPU box)
+    exchange_verified = None
+    if ex is not None:
+        o = sets[(nstep[0] - 1) % nsets]
+        g = ex.gathered(lens)
+        h_nnz = o["pair_nnz"].cpu().numpy().view(np.uint32)
+        h_off = o["pair_off"].cpu().numpy().view(np.uint64)
+        h_rp = o["rowptr"].cpu().numpy().view(np.uint32)
+        h_col = o["col"].cpu().numpy().view(np.uint32)
+        h_val = o["val"].cpu().numpy()
+        h_sim = o["sim"].cpu().numpy()
+        exchange_verified = 0
+        for k in range(0, np_local, max(1, np_local // 256)):
+            x, y = int(px[k]), int(py[k])
+            n, base, l1, l2 = int(h_nnz[k]), int(h_off[k]), int(lens[x]) + 1, int(lens[y]) + 1
+            r0 = int(rp_off[k])
+            for tr in (False, True):
+                grp, gcol, gval = g.csr(y, x) if tr else g.csr(x, y)
+                rp = h_rp[r0 + l1:r0 + l1 + l2] if tr else h_rp[r0:r0 + l1]
+                e0 = base + (n if tr else 0)
+                if not (np.array_equal(grp, rp) and np.array_equal(gcol, h_col[e0:e0 + n]) and gval.tobytes() == h_val[e0:e0 + n].tobytes()):
+                    raise SystemExit("bench: pair (%d, %d) differs after the exchange" % (x, y))
+            if np.float32(g.sim(x, y)).tobytes() != np.float32(h_sim[k]).tobytes():
+                raise SystemExit("bench: similarity of pair (%d, %d) differs after the exchange" % (x, y))
+            exchange_verified += 1
+
     e2e = None
     dd_forced = None
     stages = None
@@ -525,6 +553,9 @@ def main():
             "cpu_baseline": cpu,
             "verified_pairs": verified,
         }
+        if exchange_verified is not None:
+            out["exchange"] = {"backend": dist.get_backend(), "world": world, "verified_pairs": exchange_verified,
+                               "slab_bytes_per_rank": int(ex.send.numel()) * 4}
         if e2e is not None:
             out["end_to_end"] = e2e
             out["stages"] = stages

@@ -229,6 +229,64 @@ class Pipeline:
             pass
 
 
+def _phase1_worker(job):
+    """one worker of parallel_oracle_run: base-pairing rows of its sequences and matching rows of its pairs (CPU only)"""
+    seqs, xs, pairs, model, th = job
+    orc = load_oracle()
+    bp = {}
+    for x in xs:
+        L = len(seqs[x])
+        rp = np.zeros(L + 1, np.uint32); col = np.zeros(L * (L + 1) // 2 + 1, np.uint32); val = np.zeros(L * (L + 1) // 2 + 1, np.float32)
+        n = orc.lib.orc_fold_calculate(seqs[x].encode(), L, None, C.c_float(0.01), rp.ctypes.data, col.ctypes.data, val.ctypes.data)
+        assert n >= 0
+        bp[x] = (rp, col[:n].copy(), val[:n].copy())
+    mp = {(x, y): orc.align_calculate(seqs[x], seqs[y], th, model) for x, y in pairs}
+    return bp, mp
+
+
+def _parallel_oracle_main():
+    """child process of parallel_oracle_run (python oracle_lib.py --run): job as JSON on stdin, result as JSON on stdout"""
+    import json
+    import multiprocessing as mp
+    import os
+    import sys
+    job = json.load(sys.stdin)
+    names, seqs, params = job["names"], job["seqs"], job["params"]
+    model = params.pop("align_model", 0)
+    th = params.get("th_a", 0.01)
+    n = len(seqs)
+    workers = job.get("workers") or min(len(os.sched_getaffinity(0)), 16)
+    pairs = [(x, y) for x in range(n) for y in range(x + 1, n)]
+    jobs = [(seqs, list(range(w, n, workers)), pairs[w::workers], model, th) for w in range(workers)]
+    with mp.get_context("fork").Pool(workers) as pool:  # this process never touches a GPU
+        parts = pool.map(_phase1_worker, jobs)
+    bp, rows = {}, {}
+    for b, m in parts:
+        bp.update(b); rows.update(m)
+    orc = load_oracle()
+    pl = orc.pipeline(names, seqs, orc.params(fold_model=1, align_model=2, **params), bp=[bp[x] for x in range(n)], mp=lambda x, y: rows[(x, y)])
+    pl.phase1(); pl.phase2()
+    it, vi = pl.dd_log()
+    json.dump({"output": pl.output(), "iterations": [int(v) for v in it], "violated": [int(v) for v in vi], "seconds": pl.seconds()}, sys.stdout)
+    pl.close()
+
+
+def parallel_oracle_run(names, seqs, workers=None, **params):
+    """The oracle's whole run with its phase-1 models computed process-parallel (the reference has no threading; this only
+    shortens the checker): CONTRAfold rows and matching rows of the chosen align_model come from worker processes and enter
+    the pipeline through its --fold-aux / --align-aux paths (orc_pipeline_set_bp / _set_mp); consistency transforms, tree
+    and progressive phase run on one core.  All of it in a child process of its own (the caller may hold a GPU context).
+    Returns (output text, (iterations, violated) log)."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--run"], input=json.dumps({"names": names, "seqs": seqs, "params": params, "workers": workers}),
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle run failed:\n" + r.stderr[-2000:])
+    d = json.loads(r.stdout)
+    return d["output"], (np.array(d["iterations"], np.uint32), np.array(d["violated"], np.uint32))
+
+
 def load_oracle():
     path = os.path.join(ORACLE_DIR, "liboracle.so")
     if not os.path.exists(path) or os.path.exists("/root/reference/src/dafs.cpp"):
@@ -348,3 +406,9 @@ def load_ref():
     if not os.path.exists(path):
         return None
     return Ref(C.CDLL(path))
+
+
+if __name__ == "__main__":
+    import sys
+    if "--run" in sys.argv:
+        _parallel_oracle_main()

@@ -129,6 +129,22 @@ def test_c4_whole_run_properties(which):
         assert a.output == b.output and a.dd_log == b.dd_log
 
 
+def test_c4_family_whole_run_equals_oracle():
+    """BASELINE config 4 (N=256, L~200, ProbCons + CONTRAfold), family set, end to end against the CPU port, bit for bit
+    (output text and iteration log; parity unpinned for the dafs.cpp half).  The oracle's 32 640 pair posteriors and 256
+    folds run process-parallel, the rest of it on one core."""
+    import oracle_lib
+    from dafs_amd import pipeline
+    _, (names, seqs) = _sets(256, 200)
+    t0 = time.time()
+    want, (it, vi) = oracle_lib.parallel_oracle_run(names, seqs)
+    print("oracle: %.1f s" % (time.time() - t0))
+    got = pipeline.run(names, seqs, skip_uncoupled_folds=False)
+    assert got.output == want
+    assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
+    assert sorted(v[1] for v in got.dd_log.values()) == sorted(int(x) for x in vi)
+
+
 # ---------------------------------------------------------------------------------------------- c5
 def test_c5_contralign_pairs_in_shards(oracle):
     """130 816 CONTRAlign pairs at L~400 in eight pair-index shards; properties of all, the oracle on every 1201st"""

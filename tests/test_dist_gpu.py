@@ -67,3 +67,19 @@ def test_sharded_run_equals_single_process(world, model):
         assert not out.startswith("FAILED"), out
         assert out == want.output, rank
         assert sim == want_sim, rank
+
+
+def test_rccl_exchange_on_one_rank():
+    """The packed-slab all-gather of bench.py's multi-GPU step through the nccl backend (= RCCL on ROCm), world size 1 on the
+    box's one GPU: DAFS_BENCH_FORCE_EXCHANGE=1 makes the single rank run the exchange path (two output sets, gather on a
+    communication stream), and bench.py checks every sampled pair of the gathered slab against the kernel's own output."""
+    import json
+    import subprocess
+    env = dict(os.environ, DAFS_BENCH_FORCE_EXCHANGE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--config", "c2",
+                        "--no-cpu", "--no-e2e"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["exchange"]["backend"] == "nccl" and line["exchange"]["world"] == 1
+    assert line["exchange"]["verified_pairs"] >= 200 and line["verified_pairs"] > 0

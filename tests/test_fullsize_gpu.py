@@ -73,3 +73,18 @@ def test_whole_run_properties(headline):
     assert depth == 0
     its = [v[0] for v in a.dd_log.values()]
     assert len(its) == N - 1 and max(its) <= 600
+
+
+def test_whole_run_equals_oracle(headline):
+    """BASELINE config 3 end to end against the CPU port, bit for bit: tree line, structure line, every alignment row and the
+    per-node iteration log (parity unpinned for the dafs.cpp half).  The oracle's models run process-parallel
+    (oracle_lib.parallel_oracle_run), its transforms, tree and progressive phase on one core."""
+    import oracle_lib
+    from dafs_amd import pipeline
+    names, seqs = headline
+    want, (it, vi) = oracle_lib.parallel_oracle_run(names, seqs)
+    got = pipeline.run(names, seqs, skip_uncoupled_folds=False)
+    assert got.output == want
+    assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
+    assert sorted(v[1] for v in got.dd_log.values()) == sorted(int(x) for x in vi)
+    assert pipeline.run(names, seqs).output == want          # the drivers' default (uncoupled foldings left out)

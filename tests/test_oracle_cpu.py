@@ -89,6 +89,22 @@ def test_pipeline_with_supplied_matching_rows(oracle):
     c.close()
 
 
+def test_parallel_oracle_run_equals_the_serial_one(oracle):
+    """oracle_lib.parallel_oracle_run (models in worker processes, fed through the --fold-aux / --align-aux paths) is the
+    serial pipeline, text and iteration log"""
+    import oracle_lib
+    recs = synth.family_set(9, 50, seed=3) + synth.random_set(3, 40, seed=4)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    for model in (0, 1):
+        out, (it, vi) = oracle_lib.parallel_oracle_run(names, seqs, workers=3, align_model=model)
+        pl = oracle.pipeline(names, seqs, oracle.params(fold_model=0, align_model=model))
+        pl.phase1(); pl.phase2()
+        assert out == pl.output()
+        sit, svi = pl.dd_log()
+        assert list(it) == list(sit) and list(vi) == list(svi)
+        pl.close()
+
+
 def test_probcons_known_scalars(oracle):
     ka = known()
     seqs = [s for _, s in oracle.fasta(os.path.join(G, "RF00005_0.fa"))]

@@ -1,9 +1,4 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 300 python -m pytest tests/test_pct_gpu.py -x -q > gpurun_out/r3_pct_tests.log 2>&1; rc=$?; tail -5 gpurun_out/r3_pct_tests.log
-[ $rc -ne 0 ] && exit $rc
-python tools/scratch/pct_time.py 128 150 2>&1 | grep -v amdgpu.ids | tail -1
-python tools/scratch/pct_time.py 256 200 2>&1 | grep -v amdgpu.ids | tail -1
-python tools/scratch/pct_time.py 128 150 family 2>&1 | grep -v amdgpu.ids | tail -1
-DAFS_HIP_PCT_GRID2D=1 python tools/scratch/pct_time.py 128 150 2>&1 | grep -v amdgpu.ids | tail -1
+timeout -k 10 900 python -m pytest tests/test_dist_gpu.py tests/test_fullsize_gpu.py tests/test_configs_gpu.py -x -q -s --durations=10 -k "rccl or whole_run_equals_oracle or c4_family_whole" > gpurun_out/r3_newtests.log 2>&1; rc=$?; tail -25 gpurun_out/r3_newtests.log
 exit $rc
