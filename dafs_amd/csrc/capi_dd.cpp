@@ -208,6 +208,10 @@ dd_params device_params(const dafs_dd_params* prm) {
   dp.stamps = getenv("DAFS_HIP_DD_STAMPS") ? 1 : 0;
   dp.skip_xy = prm->skip_uncoupled_folds ? 1 : 0;
   dp.debug_lose_folders = getenv("DAFS_HIP_DD_LOSE_FOLDERS") ? 1 : 0;
+  {
+    const char* e = getenv("DAFS_HIP_DD_SPAN_MW");
+    dp.span_one_wave = (e && atoi(e) == 0) ? 1 : 0;
+  }
   dp.slice = 0;
   dp.budget = 0; dp.t_ref = nullptr; dp.t_ref_write = 0;
   return dp;
@@ -375,8 +379,14 @@ int nodes_open_impl(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const d
         split_lds[b] = 0;
         // Nodes whose foldings cannot take the span form side by side, but can on a workgroup of their own, are worth
         // splitting even when the column-owning forms fit side by side: the span form is about twice as fast.
-        const bool span_folders = span_allowed && !force_wide && !(nd.lds_flags & 64u) && L1 <= DD_SPAN_LMAX && L2 <= DD_SPAN_LMAX &&
-                                  (size_t)dd_span_words(std::max(L1, L2)) * 4 + 16 <= kDdLdsBudget;
+        // ... and since round 3 also when they do fit side by side, as soon as a folding has more than one row slot: its
+        // folder shares the slots out to its wavefronts (nuss_span_mw: a span costs one slot step + a barrier instead of
+        // one slot step per live slot), which the node's own workgroup -- one wavefront per subproblem -- cannot do.
+        const char* mw_env = getenv("DAFS_HIP_DD_SPAN_MW");
+        const bool mw_allowed = !(mw_env && atoi(mw_env) == 0);
+        const bool span_folders = span_allowed && !force_wide && L1 <= DD_SPAN_LMAX && L2 <= DD_SPAN_LMAX &&
+                                  (size_t)dd_span_words(std::max(L1, L2)) * 4 + 16 <= kDdLdsBudget &&
+                                  (!(nd.lds_flags & 64u) || (mw_allowed && std::max(L1, L2) > 64));
         if ((!(nd.lds_flags & (2u | 64u)) || span_folders) && !force_wide) {
           size_t worst = 0;
           const uint32_t Ls[2] = {L1, L2};

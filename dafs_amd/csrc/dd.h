@@ -67,6 +67,7 @@ struct dd_params {
   int force_iters;
   int stamps;  // accumulate per-phase timing into info[8..13] (tuning aid)
   int skip_xy; // dafs_dd_params::skip_uncoupled_folds
+  int span_one_wave;       // DAFS_HIP_DD_SPAN_MW=0 (tests, tuning): the folders keep the span form on one wavefront
   int debug_lose_folders;  // DAFS_HIP_DD_LOSE_FOLDERS=1 (tests): the leader of a split node treats its folders as lost at once
   uint32_t slice;  // at most this many iterations per launch (0 = run to the end); a node that is cut short is
                    // marked paused and continues from where it stopped at the next launch

@@ -577,6 +577,115 @@ __device__ float nuss_wave_span(uint32_t L_, const float* S_, uint32_t* trb_, fl
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(prev[0])));  // dp[0][L-1]: row 0, last span
 }
 
+// The span form on one wavefront PER ROW SLOT (round 3), for a folding that has a workgroup of its own (split mode): wave r
+// owns rows 64 r .. 64 r + 63, all waves of the workgroup walk the spans together, one workgroup barrier per span.  The
+// single wavefront above visits its row slots one after the other -- sum over the slots of the spans they live, 297 slot
+// steps at L = 163 --; here a span costs one slot step plus the barrier, L - 3 of them.  What crosses the wavefronts goes
+// through LDS, which holds it anyway: lane 63 reads dp[i+1][j] of the slot above from the triangle (wave r + 1 wrote it in
+// the previous span), and the candidate lists of the next span's columns are fetched after the barrier, when every wave's
+// insertions of this span are in.  (Round 2's attempt kept the waves in step with LDS mailboxes they polled: the polling
+// slowed the LDS for the waves at work.  s_barrier costs nothing while waiting.)  Same cells, same order per cell, same
+// codes, candidate lists and overflow rule as nuss_wave_span: bit-identical, and nuss_traceback_fast serves both.
+// Every wave of the workgroup must call it (waves without a slot only keep the barriers).  Returns dp[0][L-1] in wave 0.
+__device__ __noinline__ float nuss_span_mw(uint32_t L_, const float* S_, uint32_t* trb_, float* tri_, float* cval_, uint32_t* ckof_, uint32_t* lck_, int wave, int lane,
+                                           bool* ovf_out) {
+  const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)L_);
+  const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
+  DD_GLB const float* S = (DD_GLB const float*)S_;
+  DD_LDS uint32_t* trb = (DD_LDS uint32_t*)trb_;
+  DD_LDS char* tri = (DD_LDS char*)tri_;
+  DD_LDS char* cval = (DD_LDS char*)cval_;
+  DD_LDS char* ckof = (DD_LDS char*)ckof_;
+  DD_LDS uint32_t* lck = (DD_LDS uint32_t*)lck_;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  const uint32_t Lp = (L + 63) & ~63u;
+  const uint32_t i = (uint32_t)lane + 64u * r;       // this lane's row
+  const bool slot = 64u * r < L;                     // (scalar) this wave has rows at all
+  const uint32_t ic = i < L ? i : 0u;
+  const uint32_t qrow = (uint32_t)tri_index(L, ic, ic);
+  const uint32_t rb = (qrow - ic) * 4u;
+  // dp[i+1][j] of lane 63's neighbour row 64 (r + 1): cell (i + 1, i + 1 + (d - 1)) of the triangle
+  const uint32_t inext = i + 1 < L ? i + 1 : 0u;
+  const uint32_t qnext = (uint32_t)tri_index(L, inext, inext);
+  float prev = 0.0f, dg = 0.0f;
+  constexpr int PF = 4;
+  float sq[PF];
+#pragma unroll
+  for (int k = 0; k < PF; ++k) {
+    sq[k] = 0.0f;
+    if (slot && 3u + k < L && i < L - (3u + k)) sq[k] = S[(size_t)(3u + k) * Lp + i];
+  }
+  bool ovf = false;
+  v4f cv;
+  v4u ck;
+  {
+    const uint32_t jn = i + 3 < L ? i + 3 : L;  // entry L: the always-empty list
+    cv = *(DD_LDS const v4f*)(cval + jn * 16u);
+    ck = *(DD_LDS const v4u*)(ckof + jn * 16u);
+  }
+  for (uint32_t d0 = 3; d0 < L; d0 += PF) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const uint32_t d = d0 + k;
+      if (d >= L) break;
+      const uint32_t ncell = L - d;               // rows 0 .. ncell - 1 have a cell of this span
+      if (slot && 64u * r < ncell) {              // (scalar) this slot still lives
+        const float s = sq[k];
+        if (d + PF < L) sq[k] = (i < L - (d + PF)) ? S[(size_t)(d + PF) * Lp + i] : 0.0f;
+        DD_LDS const char* row = tri + rb;
+        const float dk0 = *(DD_LDS const float*)(row + ck.x), dk1 = *(DD_LDS const float*)(row + ck.y);
+        const float dk2 = *(DD_LDS const float*)(row + ck.z), dk3 = *(DD_LDS const float*)(row + ck.w);
+        const float across = *(DD_LDS const float*)(tri + (qnext + (d - 1)) * 4u);  // lane 63's neighbour lives in the next wave
+        int b = __builtin_amdgcn_update_dpp(0, __float_as_int(prev), 0x130, 0xf, 0xf, false);  // wave_shl:1: lane l takes lane l+1
+        const float below = lane == 63 ? across : __int_as_float(b);
+        const bool valid = i < ncell;
+        const uint32_t j = i + d;
+        float v = below;                          // nussinov.cpp:226-233
+        uint32_t t = 1u;
+        const bool m2 = v < prev;
+        v = m2 ? prev : v; t = m2 ? 2u : t;
+        const float cand = dg + s;                // :236
+        const bool pos = s > 0.0f;
+        const bool m3 = pos && v < cand;
+        v = m3 ? cand : v; t = m3 ? 3u : t;
+        const float cvx[DD_CAP] = {cv.x, cv.y, cv.z, cv.w};
+        const float dk[DD_CAP] = {dk0, dk1, dk2, dk3};
+#pragma unroll
+        for (int x = 0; x < DD_CAP; ++x) {        // bifurcations, oldest candidate first (:245-255)
+          const float cx = dk[x] + cvx[x];
+          const bool m = v < cx;
+          v = m ? cx : v; t = m ? (uint32_t)(4 + x) : t;
+        }
+        if (valid) {
+          const uint32_t q = qrow + d;
+          *(DD_LDS float*)(tri + q * 4u) = v;
+          __hip_atomic_fetch_or(&trb[q >> 3], t << ((q & 7u) * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (valid && pos) {                       // a new candidate for column j (slots fill in order: count the occupied ones)
+          const uint32_t nc = (cvx[0] > -INFINITY ? 1u : 0u) + (cvx[1] > -INFINITY ? 1u : 0u) + (cvx[2] > -INFINITY ? 1u : 0u) + (cvx[3] > -INFINITY ? 1u : 0u);
+          if (nc < DD_CAP) {
+            *(DD_LDS float*)(cval + j * 16u + nc * 4u) = cand;
+            *(DD_LDS uint32_t*)(ckof + j * 16u + nc * 4u) = i ? (i - 1) * 4u : 0u;
+            lck[nc * L + j] = i;
+          } else ovf = true;
+        }
+        dg = below;
+        prev = v;
+      }
+      __syncthreads();                            // this span's values and insertions are in
+      if (slot) {                                 // the lists of the next span's columns (a row on its last span reads the empty list)
+        const uint32_t jn = i + d + 1;
+        const uint32_t jc = jn < L ? jn : L;
+        cv = *(DD_LDS const v4f*)(cval + jc * 16u);
+        ck = *(DD_LDS const v4u*)(ckof + jc * 16u);
+      }
+    }
+  }
+  *ovf_out = __any(ovf);
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(prev)));  // wave 0: dp[0][L-1] (row 0, last span)
+}
+
 __device__ __noinline__ float nuss_wave_span_t(uint32_t L, const float* S, uint32_t* trb, float* tri, float* cval, uint32_t* ckof, uint32_t* lck, int lane, bool* ovf) {
   switch ((L + 63) / 64) {
     case 1: return nuss_wave_span<1>(L, S, trb, tri, cval, ckof, lck, lane, ovf);
@@ -1528,6 +1637,7 @@ __device__ __forceinline__ void dd_folder(const dd_node& nd, const dd_params& pr
   float* P = (float*)s_dd;  // traceback stack of the register form: inside its ring, which is idle by then
   // span form (fold_fast bit 4 / 5): codes, dp triangle, candidate values and row offsets, split rows -- as in k_dd_solve
   const bool span = (nd.fold_fast & (isx ? 16u : 32u)) != 0;
+  const bool span_mw = L > 64 && !prm.span_one_wave;  // a wavefront per row slot (one slot: nothing to share out)
   float *tri = nullptr, *cvl = nullptr;
   uint32_t* ckl = nullptr;
   if (span) {
@@ -1554,6 +1664,21 @@ __device__ __forceinline__ void dd_folder(const dd_node& nd, const dd_params& pr
     __syncthreads();
     // The register form first, unless there is none for this width (beyond 768 columns, or no room) or it has
     // already overflowed its DD_CAP candidates per column in this launch (dense inputs do so every time).
+    if (span && !gave_up && span_mw) {
+      // a wavefront per row slot, a barrier per span (nuss_span_mw); the traceback stays with wave 0
+      if (tid == 0) s_slow = 0;
+      __syncthreads();
+      bool slow = true;
+      const float sc = nuss_span_mw(L, isx ? nd.s_xs : nd.s_ys, trbp, tri, cvl, ckl, lck, wave, lane, &slow);
+      if (slow && lane == 0) atomicOr(&s_slow, 1u);
+      __syncthreads();
+      if (wave == 0) {
+        if (!s_slow) nuss_traceback_fast(L, trbp, trb_g, lck, ss, (uint32_t*)P, lane);
+        if (lane == 0) s_fscore = sc;
+      }
+      __syncthreads();
+      gave_up = s_slow != 0;
+    } else
     if ((span || (ring && W <= DD_WFOLD)) && !gave_up) {
       if (wave == 0) {
         bool slow = true;

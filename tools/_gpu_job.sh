@@ -1,4 +1,7 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_dist_gpu.py tests/test_fullsize_gpu.py tests/test_configs_gpu.py -x -q -s --durations=10 -k "rccl or whole_run_equals_oracle or c4_family_whole" > gpurun_out/r3_newtests.log 2>&1; rc=$?; tail -25 gpurun_out/r3_newtests.log
-exit $rc
+timeout -k 10 600 python -m pytest tests/test_dd_gpu.py -x -q --durations=5 > gpurun_out/r3_dd_tests.log 2>&1; rc=$?; tail -12 gpurun_out/r3_dd_tests.log
+[ $rc -ne 0 ] && exit $rc
+python tools/time_stages.py 128 150 2>&1 | grep -v amdgpu.ids | tail -3
+DAFS_HIP_DD_SPAN_MW=0 python tools/time_stages.py 128 150 2>&1 | grep -v amdgpu.ids | tail -3
+exit 0
