@@ -139,6 +139,12 @@ _update_basepairing = _sig("dafs_hip_update_basepairing", C.c_int, [C.c_void_p, 
 _consensus_structure = _sig("dafs_hip_consensus_structure", C.c_int,
                             [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                              C.POINTER(C.c_float), C.c_void_p])
+_mp_export_dev = _sig("dafs_hip_mp_export_dev", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64] + [C.c_void_p] * 5 + [C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
+_mp_install_dev = _sig("dafs_hip_mp_install_dev", C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_uint64])
+_bp_export_dev = _sig("dafs_hip_bp_export_dev", C.c_int, [C.c_void_p] + [C.c_void_p] * 3 + [C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
+_set_bp_dev = _sig("dafs_hip_set_bp_dev", C.c_int, [C.c_void_p, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint64])
+
+
 class StageTime(C.Structure):
     _fields_ = [("kernel", C.c_char_p), ("ms", C.c_double), ("longest_ms", C.c_double), ("launches", C.c_uint32)]
 
@@ -454,6 +460,35 @@ class Context:
         r, u, p = C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(_nodes_memory(self._h, C.byref(r), C.byref(u), C.byref(p)))
         return r.value, u.value, p.value
+
+    # --- device-resident exchange of the stores (device pointers as integers, e.g. torch.Tensor.data_ptr()) ---
+    def mp_sizes(self, relaxed):
+        """(pairs, entries = 2 * sum of nnz, row pointers) of a matching store"""
+        npairs, nnz, nrp = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(_mp_result_size(self._h, relaxed, C.byref(npairs), C.byref(nnz), C.byref(nrp)))
+        return npairs.value, 2 * nnz.value, nrp.value
+
+    def mp_export_dev(self, relaxed, first, count, nnz, rowptr, col, val, sim, cap_entries):
+        nr, ne = C.c_uint64(), C.c_uint64()
+        check(_mp_export_dev(self._h, relaxed, first, count, nnz, rowptr, col, val, sim, cap_entries, C.byref(nr), C.byref(ne)))
+        return nr.value, ne.value
+
+    def mp_install_dev(self, relaxed, nnz, rowptr, col, val, sim, n_entries):
+        check(_mp_install_dev(self._h, relaxed, nnz, rowptr, col, val, sim, n_entries))
+
+    def bp_sizes(self, relaxed=0):
+        nnz, nrp = C.c_uint64(), C.c_uint64()
+        check(_bp_result_size(self._h, relaxed, C.byref(nnz), C.byref(nrp)))
+        return nnz.value, nrp.value
+
+    def bp_export_dev(self, rowptr, col, val, cap_entries):
+        nr, ne = C.c_uint64(), C.c_uint64()
+        check(_bp_export_dev(self._h, rowptr, col, val, cap_entries, C.byref(nr), C.byref(ne)))
+        return nr.value, ne.value
+
+    def set_bp_dev(self, seq_of_block, rowptr, col, val, n_entries):
+        order = np.ascontiguousarray(seq_of_block, np.uint32)
+        check(_set_bp_dev(self._h, len(order), order.ctypes.data, rowptr, col, val, n_entries))
 
     def stage_timing(self, enable=True):
         """per-kernel device timings on / off (dafs_hip_stage_timing: HIP events around every launch of the library)"""

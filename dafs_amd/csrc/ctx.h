@@ -61,7 +61,7 @@ struct mp_store {
   dev_buf<uint64_t> pair_off, rp_off;
   mp_store_dev view(const uint32_t* d_len, uint32_t nseq) const {
     mp_store_dev v;
-    v.rowptr_pool = rowptr_pool.ptr; v.col = col.ptr; v.val = val.ptr; v.ent2 = nullptr; v.ident2 = nullptr; v.pair_off = pair_off.ptr;
+    v.rowptr_pool = rowptr_pool.ptr; v.col = col.ptr; v.val = val.ptr; v.ent2 = nullptr; v.ident2 = nullptr; v.ident_rp = nullptr; v.pair_off = pair_off.ptr;
     v.pair_nnz = pair_nnz.ptr; v.rp_off = rp_off.ptr; v.task_of_pair = d_task_of_pair.ptr; v.len = d_len; v.nseq = nseq;
     return v;
   }

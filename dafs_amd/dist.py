@@ -193,13 +193,109 @@ def pair_ranges(npairs, world):
     return [npairs * k // world for k in range(world + 1)]
 
 
+def gather_parts(dist, parts, device):
+    """The one collective of an exchange: every rank contributes a list of 1-D 4-byte tensors on `device` (the same number
+    on every rank, lengths differ); returns, per part, the concatenation over the ranks in rank order -- on the device.
+    One tiny all-gather of the lengths (the strides have to be agreed), then ONE all_gather_into_tensor of the packed,
+    max-padded slab.  With the nccl backend (RCCL over xGMI) nothing touches host memory; gloo, which the CPU-side tests
+    use, carries the slab through the host."""
+    import torch
+    world = dist.get_world_size()
+    nccl = dist.get_backend() == "nccl"
+    cdev = device if nccl else torch.device("cpu")
+    mine = torch.tensor([int(p.numel()) for p in parts], dtype=torch.int64, device=cdev)
+    allsz = torch.empty(world * len(parts), dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(allsz, mine)
+    sizes = allsz.cpu().numpy().reshape(world, len(parts))
+    strides = sizes.max(axis=0)
+    offs = np.concatenate([[0], np.cumsum(strides)])
+    total = int(offs[-1])
+    if total == 0:
+        return [p[:0] for p in parts]
+    slab = torch.zeros(total, dtype=torch.int32, device=device)
+    for k, p in enumerate(parts):
+        if p.numel():
+            slab[int(offs[k]):int(offs[k]) + p.numel()] = p.view(torch.int32)
+    recv = torch.empty(world * total, dtype=torch.int32, device=cdev)
+    dist.all_gather_into_tensor(recv, slab if nccl else slab.cpu())
+    if not nccl:
+        recv = recv.to(device)
+    out = []
+    for k, p in enumerate(parts):
+        segs = [recv[r * total + int(offs[k]):r * total + int(offs[k]) + int(sizes[r, k])] for r in range(world)]
+        out.append(torch.cat(segs).view(p.dtype))
+    # the results go to the library next, which works on a stream of its own: what torch has queued (copies, concatenations)
+    # must have landed before it reads them
+    if device.type == "cuda":
+        torch.cuda.current_stream(device).synchronize()
+    return out
+
+
 def phase1_sharded(ctx, seqs, dist, device, align_model, th_a, w_pct_a, w_pct_s, fold_th=0.01):
-    """Phase 1 of DAFS::run (dafs.cpp:1787-1827) on `world` ranks, one context (one GPU) each:
-      * base-pairing posteriors of the sequences x = rank (mod world), gathered and set on every rank (set_bp);
-      * pair posteriors + similarity scores of this rank's pair-index range, gathered, installed (mp_install);
-      * relax_matching_probability for this rank's range of OUTPUT pairs, gathered, installed as the relaxed store;
+    """Phase 1 of DAFS::run (dafs.cpp:1787-1827) on `world` ranks, one context (one GPU) each, device-resident:
+      * base-pairing posteriors of the sequences x = rank (mod world): exported to device buffers, ONE all-gather, installed
+        by block (dafs_hip_bp_export_dev / dafs_hip_set_bp_dev);
+      * pair posteriors + similarity scores of this rank's contiguous pair-index range: ONE all-gather, installed
+        (dafs_hip_mp_export_dev / _install_dev) -- concatenating the ranks' ranges in rank order IS the whole in pair order;
+      * relax_matching_probability for this rank's range of OUTPUT pairs: ONE more all-gather, installed as the relaxed store;
       * relax_basepairing_probability replicated (milliseconds).
-    Afterwards ctx is in the state a single-GPU phase 1 leaves it in, bit for bit."""
+    Afterwards ctx is in the state a single-GPU phase 1 leaves it in, bit for bit.  torch supplies the buffers and the
+    collective (gather_parts); no array of the stores passes through host memory on the nccl backend."""
+    import torch
+    from . import capi
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n = len(seqs)
+    npairs = n * (n - 1) // 2
+    i32 = lambda k: torch.empty(max(int(k), 1), dtype=torch.int32, device=device)
+    f32 = lambda k: torch.empty(max(int(k), 1), dtype=torch.float32, device=device)
+    ctx.set_sequences(seqs)
+    # ---- folds: x = rank mod world, in a context of their own ----
+    mine = list(range(rank, n, world))
+    rp_t, col_t, val_t = i32(0)[:0], i32(0)[:0], f32(0)[:0]
+    if mine:
+        fc = capi.Context(ctx.device_index)
+        try:
+            fc.set_sequences([seqs[x] for x in mine])
+            fc.fold_posteriors(fold_th)
+            ne, nr = fc.bp_sizes(0)
+            rp_b, col_b, val_b = i32(nr), i32(ne), f32(ne)
+            nr, ne = fc.bp_export_dev(rp_b.data_ptr(), col_b.data_ptr(), val_b.data_ptr(), ne)
+            rp_t, col_t, val_t = rp_b[:nr], col_b[:ne], val_b[:ne]
+        finally:
+            fc.close()
+    rp_g, col_g, val_g = gather_parts(dist, [rp_t, col_t, val_t], device)
+    order = [x for r in range(world) for x in range(r, n, world)]  # sequence of the k-th gathered block
+    ctx.set_bp_dev(order, rp_g.data_ptr(), col_g.data_ptr(), val_g.data_ptr(), int(col_g.numel()))
+    # ---- pair posteriors of [b0, b1) ----
+    b = pair_ranges(npairs, world)
+    cnt = b[rank + 1] - b[rank]
+    parts = [i32(0)[:0], i32(0)[:0], i32(0)[:0], f32(0)[:0], f32(0)[:0]]
+    if cnt:
+        ctx.align_posteriors(align_model, th_a, pair_begin=b[rank], pair_end=b[rank + 1], fetch=False)
+        _, ne, nr = ctx.mp_sizes(0)
+        nnz_b, rp_b, col_b, val_b, sim_b = i32(cnt), i32(nr), i32(ne), f32(ne), f32(cnt)
+        nr, ne = ctx.mp_export_dev(0, 0, cnt, nnz_b.data_ptr(), rp_b.data_ptr(), col_b.data_ptr(), val_b.data_ptr(), sim_b.data_ptr(), ne)
+        parts = [nnz_b[:cnt], rp_b[:nr], col_b[:ne], val_b[:ne], sim_b[:cnt]]
+    nnz_g, rp_g, col_g, val_g, sim_g = gather_parts(dist, parts, device)
+    ctx.mp_install_dev(0, nnz_g.data_ptr(), rp_g.data_ptr(), col_g.data_ptr(), val_g.data_ptr(), sim_g.data_ptr(), int(col_g.numel()))
+    # ---- consistency: matching transform sharded by output pair, base-pairing transform replicated ----
+    if w_pct_a != 0.0:
+        parts = [i32(0)[:0], i32(0)[:0], i32(0)[:0], f32(0)[:0]]
+        if cnt:
+            ctx.consistency_match_range(w_pct_a, b[rank], b[rank + 1])
+            _, ne, nr = ctx.mp_sizes(1)          # entries of the shard; row pointers of all pairs (the range's are exported)
+            nnz_b, rp_b, col_b, val_b = i32(cnt), i32(nr), i32(ne), f32(ne)
+            nr, ne = ctx.mp_export_dev(1, b[rank], cnt, nnz_b.data_ptr(), rp_b.data_ptr(), col_b.data_ptr(), val_b.data_ptr(), None, ne)
+            parts = [nnz_b[:cnt], rp_b[:nr], col_b[:ne], val_b[:ne]]
+        nnz_g, rp_g, col_g, val_g = gather_parts(dist, parts, device)
+        ctx.mp_install_dev(1, nnz_g.data_ptr(), rp_g.data_ptr(), col_g.data_ptr(), val_g.data_ptr(), None, int(col_g.numel()))
+    if w_pct_s != 0.0:
+        ctx.consistency_bp(w_pct_s)
+
+
+def phase1_sharded_host(ctx, seqs, dist, device, align_model, th_a, w_pct_a, w_pct_s, fold_th=0.01):
+    """The same exchange through host arrays (round 2's form, kept as the cross-check of the device-resident one in
+    tests/test_dist_gpu.py)."""
     from . import capi
     rank, world = dist.get_rank(), dist.get_world_size()
     n = len(seqs)

@@ -345,6 +345,31 @@ int dafs_hip_consensus_structure(dafs_hip_ctx* ctx, uint32_t n, uint32_t len, co
 int dafs_hip_update_basepairing(dafs_hip_ctx* ctx, uint32_t n, uint32_t len, const uint32_t* seq, const uint8_t* mask,
                                 const uint32_t* ss, float* p_out);
 
+/* ---- device-resident exchange of the sparse stores (multi-GPU runs) ---------------------------------------------------
+ * One process per GPU shards phase 1 of DAFS::run (src/dafs.cpp:1787-1827): the folds (src/fold.cpp:66-67), the pair jobs
+ * (src/align.cpp:46-50) and the output pairs of relax_matching_probability (src/dafs.cpp:265-315) are independent.  The
+ * shards travel by all-gather over RCCL; these entry points move a store to and from DEVICE buffers of the context's own
+ * device in the layouts of dafs_hip_mp_fetch / dafs_hip_bp_fetch, so nothing goes through host memory.  Every pointer
+ * argument is device memory except where noted.
+ *   dafs_hip_mp_export_dev   pairs [first, first + count) of the store's own pair order (an un-relaxed shard computed by
+ *                            dafs_hip_align_posteriors(pair_begin, pair_end) numbers its pairs from 0; the relaxed store
+ *                            keeps the global row-major index): nnz[count], the pairs' relative row pointers, their entries
+ *                            (col / val, capacity cap_entries), and for relaxed = 0 the similarity scores sim[count].
+ *                            n_rowptr / n_entries (host) receive what was written.
+ *   dafs_hip_mp_install_dev  the whole store from arrays of all N(N-1)/2 pairs in row-major order (dafs_hip_mp_install's
+ *                            arguments, on the device); n_entries = entries in col / val = 2 * sum of nnz.
+ *   dafs_hip_bp_export_dev   the un-relaxed base-pairing store, sequences in input order (dafs_hip_bp_fetch's layout).
+ *   dafs_hip_set_bp_dev      the un-relaxed base-pairing store from nblocks = N blocks in any order: block k holds the rows
+ *                            of sequence seq_of_block[k] (host array); rowptr / col / val are the blocks' arrays concatenated
+ *                            in block order -- what the ranks' exports look like after the gather. */
+int dafs_hip_mp_export_dev(dafs_hip_ctx* ctx, int relaxed, uint64_t first, uint64_t count, uint32_t* nnz, uint32_t* rowptr, uint32_t* col, float* val,
+                           float* sim, uint64_t cap_entries, uint64_t* n_rowptr, uint64_t* n_entries);
+int dafs_hip_mp_install_dev(dafs_hip_ctx* ctx, int relaxed, const uint32_t* nnz, const uint32_t* rowptr, const uint32_t* col, const float* val,
+                            const float* sim, uint64_t n_entries);
+int dafs_hip_bp_export_dev(dafs_hip_ctx* ctx, uint32_t* rowptr, uint32_t* col, float* val, uint64_t cap_entries, uint64_t* n_rowptr, uint64_t* n_entries);
+int dafs_hip_set_bp_dev(dafs_hip_ctx* ctx, uint32_t nblocks, const uint32_t* seq_of_block, const uint32_t* rowptr, const uint32_t* col, const float* val,
+                        uint64_t n_entries);
+
 /* ---- measurement aid: device time per kernel (bench.py's "stages") ----
  * dafs_hip_stage_timing(ctx, 1) makes every kernel launch of the library record a pair of HIP events on its stream
  * (one context per process at a time); dafs_hip_stage_report waits for the device, adds the elapsed times up per kernel and

@@ -159,6 +159,13 @@ def _worker_gathers(rank, world, port, q):
         assert s.dtype == np.uint32 and np.array_equal(s, np.arange(11) + 100)
         b = dd.pair_ranges(21, world)
         assert b[0] == 0 and b[-1] == 21 and all(b[k] <= b[k + 1] for k in range(world))
+        # gather_parts: the packed one-collective form phase1_sharded uses (tensors in, tensors out; ragged and empty parts)
+        tparts = [[torch.from_numpy(parts[r].view(np.int32).copy()), torch.from_numpy(fparts[r].copy())] for r in range(world)]
+        gi, gf = dd.gather_parts(dist, tparts[rank], dev)
+        assert gi.dtype == torch.int32 and np.array_equal(gi.numpy().view(np.uint32), np.concatenate(parts))
+        assert gf.dtype == torch.float32 and gf.numpy().tobytes() == np.concatenate(fparts).tobytes()
+        ge, = dd.gather_parts(dist, [torch.zeros(0, dtype=torch.int32)], dev)   # nothing from anybody
+        assert ge.numel() == 0
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback

@@ -59,7 +59,7 @@ def test_sharded_run_equals_single_process(world, model):
     procs = [mpc.Process(target=_worker, args=(r, world, port, model, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
+    res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     assert sorted(r[0] for r in res) == list(range(world))
@@ -83,3 +83,54 @@ def test_rccl_exchange_on_one_rank():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["exchange"]["backend"] == "nccl" and line["exchange"]["world"] == 1
     assert line["exchange"]["verified_pairs"] >= 200 and line["verified_pairs"] > 0
+
+
+def _worker_nccl(q, port, host_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from dafs_amd import capi, pipeline, synth
+    from dafs_amd import dist as dd
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        recs = synth.family_set(7, 60, seed=41) + synth.random_set(4, 50, seed=42)
+        names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+        if host_path:
+            dd.phase1_sharded, keep = dd.phase1_sharded_host, dd.phase1_sharded
+        ctx = capi.Context(0)
+        res = pipeline.run(names, seqs, ctx=ctx, align_model=1, shard=(dist, dev))
+        sim = ctx.sim()
+        ctx.close()
+        q.put((res.output, sim.tobytes(), dist.get_backend()))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put(("FAILED " + traceback.format_exc(), b"", ""))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("host_path", [False, True])
+def test_sharded_whole_run_over_rccl(host_path):
+    """The whole sharded run with the nccl backend (= RCCL), world size 1 on the box's one GPU: phase 1's three exchanges are
+    all_gather_into_tensor calls on DEVICE buffers (dist.gather_parts; dafs_hip_*_export_dev / *_install_dev on either
+    side), nothing of the stores passes through host memory.  Must equal the ordinary single-process run; the host-array
+    form of round 2 (phase1_sharded_host) is run through the same backend as the cross-check."""
+    import torch.multiprocessing as mp
+    from dafs_amd import capi, pipeline, synth
+    recs = synth.family_set(7, 60, seed=41) + synth.random_set(4, 50, seed=42)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    ctx = capi.Context(0)
+    want = pipeline.run(names, seqs, ctx=ctx, align_model=1)
+    want_sim = ctx.sim().tobytes()
+    ctx.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    p = mpc.Process(target=_worker_nccl, args=(q, _free_port(), host_path))
+    p.start()
+    out, sim, backend = q.get(timeout=120)
+    p.join(timeout=60)
+    assert not out.startswith("FAILED"), out
+    assert backend == "nccl" and out == want.output and sim == want_sim
