@@ -475,6 +475,32 @@ def main():
                 raise SystemExit("bench: similarity of pair (%d, %d) differs after the exchange" % (x, y))
             exchange_verified += 1
 
+    # ---- the whole sharded phase 1 (north_star: pair jobs AND the consistency transform shard by pair index): folds by
+    # x mod G, pair posteriors and the matching transform by pair-index range, three all-gathers of device slabs over RCCL
+    # (dist.phase1_sharded), the base-pairing transform replicated.  Timed like the step: barrier + synchronize on both
+    # sides, max over ranks.  Not part of `value` (the metric is the pair-posterior path); reported beside it.
+    sharded_phase1 = None
+    if world > 1 and not args.no_e2e:
+        try:
+            from dafs_amd import dist as ddist
+            sctx = capi.Context(local_rank)
+            model = capi.ALIGN_CONTRALIGN if contra else capi.ALIGN_PROBCONS
+            reps = []
+            for rep in range(3):  # the first builds the buffers
+                dist.barrier(); torch.cuda.synchronize()
+                t0p = time.perf_counter()
+                ddist.phase1_sharded(sctx, seqs, dist, dev, model, args.th, 0.25, 0.25)
+                torch.cuda.synchronize(); dist.barrier()
+                tt = torch.tensor([time.perf_counter() - t0p], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                reps.append(float(tt.item()))
+            sharded_phase1 = {"ms": min(reps[1:]) * 1e3, "first_ms": reps[0] * 1e3, "ranks": world,
+                              "what": "folds (x mod G) + pair posteriors and matching consistency transform (pair-index ranges) + 3 all-gathers of "
+                                      "device slabs + replicated base-pairing transform; every rank ends with the complete stores"}
+            sctx.close()
+        except Exception as e:  # noqa: BLE001  (an extra leg must not take the metric line down with it)
+            sharded_phase1 = {"error": repr(e)[:300]}
+
     e2e = None
     dd_forced = None
     stages = None
@@ -561,6 +587,8 @@ def main():
             out["stages"] = stages
         if dd_forced is not None:
             out["dd_forced_iterations"] = dd_forced
+        if sharded_phase1 is not None:
+            out["sharded_phase1"] = sharded_phase1
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
