@@ -1520,6 +1520,177 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes,
   if (tid == 0) { nd.info[0] = s_total; nd.info[1] = 0; nd.info[2] = 0; nd.info[3] = 0; nd.info[4] = 0; nd.info[5] = 0; nd.info[6] = 0; nd.info[7] = 0; }
 }
 
+// ---- set-up of WIDE nodes (round 3) ------------------------------------------------------------------------------------
+// k_node_lists walks the dense matrices of a node with one workgroup (four in small launches): fine at a few hundred
+// columns, 0.3 - 0.7 s per node where an alignment of 10 000 - 27 000 columns joins the tree (c5, random set: 4.5 s of the
+// run in 164 launches).  Wide launches split the same work into kernels whose grids cover the ROWS of the three
+// matrices: counts (+ the first / last column of the envelope from the same pass over p_z), a scan per matrix, the fill,
+// the table initialisation -- and a last one-workgroup kernel for what is small (envelope smoothing, consensus-pair
+// counts).  Same lists, same order, same envelope.
+struct dd_mat { const float* P; uint32_t R, C; bool upper; uint32_t* ptr; uint32_t* lst; int32_t* map; };
+__device__ __forceinline__ dd_mat dd_list_matrix(const dd_node& nd, uint32_t which) {
+  if (which == 0) return dd_mat{nd.p_x, nd.L1, nd.L1, true, nd.px_ptr, nd.px_j, nd.xmap};
+  if (which == 1) return dd_mat{nd.p_y, nd.L2, nd.L2, true, nd.py_ptr, nd.py_l, nd.ymap};
+  return dd_mat{nd.p_z, nd.L1, nd.L2, false, nd.pz_ptr, nd.pz_k, nullptr};
+}
+// grid (row blocks of 8, node, matrix), 512 threads: a wavefront per row.  fill = 0: entries > CUTOFF per row -> ptr[i + 1];
+// for p_z also the row's first / last column with p - th >= 0 (1-based, 0 = none) -> fa / la (= nd.x / nd.z, scratch
+// here as in nw_envelope).  fill = 1: the columns (and the id map) at the scanned positions.
+template <int WHICH>
+__device__ __forceinline__ void lists_rows_body(const dd_node& nd, float th_a, int fill) {
+  // (the matrix is a template argument: with the three cases merged behind one run-time selection the compiler left the
+  // p_z case's pointers unset -- a fault at address 0 on the first launch; one instantiation per matrix is also leaner)
+  const dd_mat m = dd_list_matrix(nd, (uint32_t)WHICH);
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t i = blockIdx.x * 8 + wave;
+  if (i >= m.R) return;
+  const uint32_t jbeg = m.upper ? ((i + 1) & ~63u) : 0;
+  const float* row = m.P + (size_t)i * m.C;
+  if (!fill) {
+    uint32_t c = 0, f = 0, l = 0;
+    for (uint32_t j0 = jbeg; j0 < m.C; j0 += 256) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t j = j0 + 64 * u + lane;
+        v[u] = (j < m.C && (!m.upper || j > i)) ? row[j] : (WHICH == 2 ? -1.0f : 0.0f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        c += (uint32_t)__popcll(__ballot(v[u] > DD_CUTOFF));
+        if (WHICH == 2) {  // needleman_wunsch.cpp:205-216: p - th >= 0 (padding lanes hold -1)
+          const unsigned long long e = __ballot(v[u] - th_a >= 0.0f);
+          if (e) {
+            const uint32_t k0 = j0 + 64 * u;
+            if (!f) f = k0 + (uint32_t)__ffsll((long long)e);
+            l = k0 + 64 - (uint32_t)__clzll((long long)e);
+          }
+        }
+      }
+    }
+    if (lane == 0) {
+      m.ptr[i + 1] = c;
+      if (WHICH == 2) { nd.x[i + 1] = f; nd.z[i + 1] = l; }
+    }
+    return;
+  }
+  uint32_t pos = m.ptr[i];
+  for (uint32_t j0 = jbeg; j0 < m.C; j0 += 256) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t j = j0 + 64 * u + lane;
+      v[u] = (j < m.C && (!m.upper || j > i)) ? row[j] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t j = j0 + 64 * u + lane;
+      const bool keep = v[u] > DD_CUTOFF;
+      const unsigned long long mk = __ballot(keep);
+      if (keep) {
+        const uint32_t q = pos + (uint32_t)__popcll(mk & ((1ull << lane) - 1));
+        m.lst[q] = j;
+        if (m.map) m.map[(size_t)i * m.C + j] = (int32_t)q;
+      }
+      pos += (uint32_t)__popcll(mk);
+    }
+  }
+}
+__global__ __launch_bounds__(512) void k_lists_rows(const dd_node* nodes, float th_a, int fill) {
+  const dd_node nd = nodes[blockIdx.y];
+  if (blockIdx.z == 0) lists_rows_body<0>(nd, th_a, fill);
+  else if (blockIdx.z == 1) lists_rows_body<1>(nd, th_a, fill);
+  else lists_rows_body<2>(nd, th_a, fill);
+}
+// grid (node, matrix): exclusive row pointers from the counts
+__global__ __launch_bounds__(DD_THREADS) void k_lists_scan(const dd_node* nodes) {
+  const dd_node nd = nodes[blockIdx.x];
+  uint32_t* ptr = blockIdx.y == 0 ? nd.px_ptr : (blockIdx.y == 1 ? nd.py_ptr : nd.pz_ptr);
+  const uint32_t R = blockIdx.y == 1 ? nd.L2 : nd.L1;
+  if (threadIdx.x == 0) ptr[0] = 0;
+  __syncthreads();
+  block_scan_inclusive(ptr + 1, R);
+}
+// grid (blocks of cells, node): nw_init (:262-274) over the whole table
+__global__ __launch_bounds__(256) void k_nw_init_wide(const dd_node* nodes) {
+  const dd_node nd = nodes[blockIdx.y];
+  const uint32_t W = nd.L2 + 1;
+  const size_t cells = (size_t)(nd.L1 + 1) * W;
+  for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t i = (uint32_t)(c / W), k = (uint32_t)(c % W);
+    nd.dp_z[c] = (i == 0 || k == 0) ? 0.0f : -FLT_MAX;
+    nd.tr_z[c] = (i == 0 && k == 0) ? ' ' : (k == 0 ? 'X' : (i == 0 ? 'Y' : ' '));
+  }
+}
+// the envelope's sequential smoothing passes (needleman_wunsch.cpp:218-243) over first / last columns that are already
+// there (fa = nd.x, la = nd.z): thread 0, on an LDS copy while it fits
+__device__ void nw_envelope_smooth(uint32_t L1, uint32_t L2, const uint32_t* fa, const uint32_t* la, uint32_t* env) {
+  __shared__ uint32_t s_env[2 * 4097];
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const bool in_lds = L1 <= 4096;
+  uint32_t* ev = in_lds ? s_env : env;
+  if (tid == 0) {
+    for (uint32_t i = 0; i <= L1; ++i) { ev[2 * i] = 0; ev[2 * i + 1] = 0; }
+    for (uint32_t i = 1; i <= L1; ++i) {
+      const uint32_t f = fa[i], l = la[i];
+      if (f) {
+        if (f - 1 < ev[2 * (i - 1)]) ev[2 * (i - 1)] = f - 1;
+        ev[2 * i] = f;
+      }
+      if (ev[2 * i] == 0) {
+        ev[2 * i] = ev[2 * (i - 1)];
+        ev[2 * i + 1] = ev[2 * (i - 1) + 1];
+        continue;
+      }
+      if (l - 1 > ev[2 * (i - 1) + 1]) ev[2 * (i - 1) + 1] = l - 1;
+      ev[2 * i + 1] = l;
+    }
+    ev[2 * L1 + 1] = L2;
+    for (uint32_t i = L1, v = L2; i != 0; --i) { v = v < ev[2 * i] ? v : ev[2 * i]; ev[2 * i] = v; }
+    for (uint32_t i = 0, v = 0; i != L1 + 1; ++i) { v = v > ev[2 * i + 1] ? v : ev[2 * i + 1]; ev[2 * i + 1] = v; }
+    for (uint32_t i = 1; i != L1 + 1; ++i)
+      if (ev[2 * (i - 1) + 1] < ev[2 * i]) ev[2 * i] = ev[2 * (i - 1) + 1];
+  }
+  __syncthreads();
+  if (in_lds) {
+    for (uint32_t i = tid; i < 2 * (L1 + 1); i += nt) env[i] = s_env[i];
+    __syncthreads();
+  }
+}
+// grid (node): what is left of k_node_lists once the lists, the first / last columns and the table are there
+__global__ __launch_bounds__(DD_THREADS) void k_node_lists_tail(const dd_node* nodes, dd_params prm, uint32_t* ncbp_out) {
+  const dd_node nd = nodes[blockIdx.x];
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t L1 = nd.L1, L2 = nd.L2;
+  __shared__ uint32_t s_total;
+  if (tid == 0) s_total = 0;
+  __syncthreads();
+  uint32_t mine = 0;
+  const uint32_t npx = nd.px_ptr[L1];
+  for (uint32_t e = tid; e < npx; e += nt) {  // a thread per entry of p_x: consensus base pairs (dafs.cpp:1022-1044), as in k_node_lists
+    const uint32_t i = row_of_entry(nd.px_ptr, L1, e);
+    const uint32_t j = nd.px_j[e];
+    const float px = nd.p_x[(size_t)i * L1 + j];
+    uint32_t c = 0;
+    for (uint32_t a = nd.pz_ptr[i]; a < nd.pz_ptr[i + 1]; ++a) {
+      const uint32_t k = nd.pz_k[a];
+      const float pzik = nd.p_z[(size_t)i * L2 + k];
+      for (uint32_t b = nd.py_ptr[k]; b < nd.py_ptr[k + 1]; ++b) {
+        const uint32_t l = nd.py_l[b];
+        const float pzjl = nd.p_z[(size_t)j * L2 + l];
+        if (pzjl > DD_CUTOFF && cbp_ok(nd, prm, px, nd.p_y[(size_t)k * L2 + l], pzik, pzjl)) ++c;
+      }
+    }
+    nd.cbp_cnt[e] = c;
+    mine += c;
+  }
+  atomicAdd(&s_total, mine);
+  __syncthreads();
+  nw_envelope_smooth(L1, L2, nd.x, nd.z, nd.env);
+  if (tid == 0 && ncbp_out) ncbp_out[blockIdx.x] = s_total;
+  if (tid == 0) { nd.info[0] = s_total; nd.info[1] = 0; nd.info[2] = 0; nd.info[3] = 0; nd.info[4] = 0; nd.info[5] = 0; nd.info[6] = 0; nd.info[7] = 0; }
+}
+
 __global__ __launch_bounds__(DD_THREADS) void k_node_cbp_fill(const dd_node* nodes, dd_params prm, uint32_t pxptr_lds) {
   const dd_node nd = nodes[blockIdx.x];
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
@@ -2192,6 +2363,22 @@ int dd_avg_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len, mp_
 }
 int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, dd_params prm, uint32_t* d_ncbp, hipStream_t st) {
   if (!nnodes) return DAFS_HIP_OK;
+  // wide alignments: the dense scans on grids over the rows (DAFS_HIP_DD_LISTS_WIDE=n: from n columns on; tests force it)
+  uint32_t wide_from = 1536;
+  if (const char* e = getenv("DAFS_HIP_DD_LISTS_WIDE")) wide_from = (uint32_t)atoi(e);
+  if (max_len1 && max_len1 >= wide_from) {
+    const dim3 rows((max_len1 + 7) / 8, nnodes, 3);
+    STAGE_LAUNCH(ST_NODE_LISTS, st) hipLaunchKernelGGL(k_lists_rows, rows, dim3(512), 0, st, d_nodes, prm.th_a, 0);
+    if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
+    STAGE_LAUNCH(ST_NODE_LISTS, st) hipLaunchKernelGGL(k_lists_scan, dim3(nnodes, 3), dim3(DD_THREADS), 0, st, d_nodes);
+    if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
+    STAGE_LAUNCH(ST_NODE_LISTS, st) hipLaunchKernelGGL(k_lists_rows, rows, dim3(512), 0, st, d_nodes, prm.th_a, 1);
+    if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
+    STAGE_LAUNCH(ST_NODE_LISTS, st) hipLaunchKernelGGL(k_nw_init_wide, dim3(1024, nnodes), dim3(256), 0, st, d_nodes);
+    if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
+    STAGE_LAUNCH(ST_NODE_LISTS, st) hipLaunchKernelGGL(k_node_lists_tail, dim3(nnodes), dim3(DD_THREADS), 0, st, d_nodes, prm, d_ncbp);
+    return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
+  }
   const size_t budget = 136 * 1024;  // 18 KB of static scan areas
   size_t lds = max_len1 ? ((size_t)max_len1 + 4) * 4 : 0;  // 0: forced to the HBM search (tests)
   if (lds > budget) lds = budget;  // longer row pointer arrays are searched in HBM

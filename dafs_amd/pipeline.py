@@ -95,6 +95,13 @@ def run(names, seqs, ctx=None, bp=None, w=4.0, eta0=0.5, t_max=600, w_pct_a=0.25
     matching consistency transform) is then split over the ranks and gathered (dist.phase1_sharded); every rank
     finishes the run and holds the same result."""
     import time
+    # combinations this driver does not implement are refused, not ignored (the command line, cli_main.cpp, covers
+    # --bp-update with level batches through its own solve_batch)
+    if level_sync and bp_update:
+        raise ValueError("pipeline.run: bp_update needs the resident-node schedule (level_sync=False)")
+    if shard is not None and (bp is not None or mp is not None or w_pct_f != 0.0):
+        raise ValueError("pipeline.run: a sharded phase 1 computes its posteriors itself: bp / mp (--fold-aux / --align-aux) and "
+                         "w_pct_f (-f) are single-process options")
     own = ctx is None
     if own:
         ctx = capi.Context(0)

@@ -82,3 +82,15 @@ def test_host_build_tree_matches_python_twin():
         b = pipeline.build_tree(s)
         assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_driver_refuses_option_combinations_it_does_not_implement():
+    """pipeline.run: level batches with --bp-update, or a sharded phase 1 with supplied posteriors / the four-way transform,
+    raise instead of silently dropping the option (no GPU is touched before the check)"""
+    import pytest
+    from dafs_amd import pipeline
+    with pytest.raises(ValueError):
+        pipeline.run(["a", "b"], ["ACGU", "ACGU"], ctx=object(), level_sync=True, bp_update=True)
+    for kw in (dict(bp=[]), dict(mp=()), dict(w_pct_f=0.3)):
+        with pytest.raises(ValueError):
+            pipeline.run(["a", "b"], ["ACGU", "ACGU"], ctx=object(), shard=(None, None), **kw)
