@@ -230,6 +230,27 @@ def test_wide_alignment_forms_equal_oracle(oracle):
     assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
 
 
+def test_wide_setup_kernels_equal_oracle(oracle, monkeypatch):
+    """DAFS_HIP_DD_LISTS_WIDE=1 sends every node through the set-up kernels that only alignments of 1536+ columns take (row
+    lists, envelope ends and table initialisation on grids over the rows, k_lists_rows & co.); the run -- lists, envelope,
+    consensus pairs, hence every iteration -- must still be the oracle's."""
+    from dafs_amd import pipeline
+    from test_pct_gpu import random_bp
+    recs = synth.family_set(8, 90, seed=15) + synth.random_set(3, 70, seed=16)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    bp = random_bp(seqs, 15, density=0.03)
+    pl = oracle.pipeline(names, seqs, oracle.params(fold_model=1), bp=bp)
+    pl.phase1(); pl.phase2()
+    want = pl.output()
+    it, vi = pl.dd_log()
+    pl.close()
+    monkeypatch.setenv("DAFS_HIP_DD_LISTS_WIDE", "1")
+    got = pipeline.run(names, seqs, bp=bp, skip_uncoupled_folds=False)
+    assert got.output == want
+    assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
+    assert sorted(v[1] for v in got.dd_log.values()) == sorted(int(x) for x in vi)
+
+
 def test_limits_refuse_cleanly_and_context_survives(oracle):
     """what is left of the hard limits: a pair-HMM column sequence beyond 64 lanes x 32 columns, a CONTRAfold sequence
     whose per-position tables outgrow LDS.  Each must come back as ETOOLONG (-4), and the same context must then work."""
