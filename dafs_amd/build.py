@@ -89,7 +89,11 @@ def build_cli(force=False):
     for out, srcs in targets:
         if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
             continue
-        cmd = [cxx, "-std=c++17", "-O2", "-Wall", "-o", out] + srcs + ["-L" + HERE, "-ldafs_hip", "-Wl,-rpath,$ORIGIN"]
+        rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+        cmd = [cxx, "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(rocm, "include"), "-o", out] + srcs
+        cmd += ["-L" + HERE, "-ldafs_hip", "-Wl,-rpath,$ORIGIN"]
+        if out == CLI:  # the staging copies of --devices; librccl itself is loaded on demand
+            cmd += ["-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-ldl", "-lpthread"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("host build failed:\n" + r.stderr)

@@ -44,6 +44,7 @@ extern "C" const char* dafs_hip_strerror(int code) {
     case DAFS_HIP_ETOOLONG: return "dafs_hip: sequence too long for the device kernels";
     case DAFS_HIP_EOVERFLOW: return "dafs_hip: sparse output pool overflow";
     case DAFS_HIP_ELAUNCH: return "dafs_hip: kernel launch or execution failed";
+    case DAFS_HIP_ECOMM: return "dafs_hip: the collective between the ranks failed";
     default: return "dafs_hip: unknown error";
   }
 }

@@ -262,6 +262,9 @@ int plan_check(const dd_node& nd, bool split) {
         if (!byspan) return bad("span-form folder without the by-span score copy");
         if (L > DD_SPAN_LMAX) return bad("span-form folder beyond its width");
       } else if ((nd.fold_fast & (5u << r)) && reg && !sweep) return bad("register-form folder without its sweep-order scores");
+      if (nd.fold_fast & (64u << r)) {
+        if (!byspan) return bad("workgroup-form folder without the by-span score copy");
+      }
     }
   }
   return DAFS_HIP_OK;
@@ -384,17 +387,31 @@ int nodes_open_impl(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const d
         // one slot step per live slot), which the node's own workgroup -- one wavefront per subproblem -- cannot do.
         const char* mw_env = getenv("DAFS_HIP_DD_SPAN_MW");
         const bool mw_allowed = !(mw_env && atoi(mw_env) == 0);
+        const char* wg_env = getenv("DAFS_HIP_DD_WG");
+        const bool wg_allowed = !(wg_env && atoi(wg_env) == 0);
+        const bool wg_force = wg_env && atoi(wg_env) == 2;  // tests: every folder takes the workgroup form, whatever its width
         const bool span_folders = span_allowed && !force_wide && L1 <= DD_SPAN_LMAX && L2 <= DD_SPAN_LMAX &&
                                   (size_t)dd_span_words(std::max(L1, L2)) * 4 + 16 <= kDdLdsBudget &&
                                   (!(nd.lds_flags & 64u) || (mw_allowed && std::max(L1, L2) > 64));
-        if ((!(nd.lds_flags & (2u | 64u)) || span_folders) && !force_wide) {
+        if ((!(nd.lds_flags & (2u | 64u)) || span_folders || wg_force) && !force_wide) {
           size_t worst = 0;
           const uint32_t Ls[2] = {L1, L2};
           for (int r = 0; r < 2; ++r) {
             const uint32_t L = Ls[r];
-            if (span_folders) { nd.fold_fast |= 16u << r; worst = std::max(worst, (size_t)dd_span_words(L) * 4 + 16); }
-            else if (wide_ok(L, DD_WREG) && fast(L) <= kDdLdsBudget) { nd.fold_fast |= 1u << r; worst = std::max(worst, fast(L)); }
-            else if (wide_ok(L, DD_WFOLD) && fast_g(L) <= kDdLdsBudget) { nd.fold_fast |= 4u << r; worst = std::max(worst, fast_g(L)); }
+            const bool no_reg = !wide_ok(L, DD_WFOLD) || wg_force;
+            if (span_folders && !wg_force) { nd.fold_fast |= 16u << r; worst = std::max(worst, (size_t)dd_span_words(L) * 4 + 16); }
+            else if (!no_reg && wide_ok(L, DD_WREG) && fast(L) <= kDdLdsBudget) { nd.fold_fast |= 1u << r; worst = std::max(worst, fast(L)); }
+            else if (!no_reg && wide_ok(L, DD_WFOLD) && fast_g(L) <= kDdLdsBudget) { nd.fold_fast |= 4u << r; worst = std::max(worst, fast_g(L)); }
+            else if (no_reg && wg_allowed) {
+              // no register form: the workgroup form with as many candidates per column on chip as fit (dd_wg_words); beyond
+              // ~10 000 columns not even its rolling rows fit and the span-ordered form on HBM tables remains
+              for (uint32_t K : {4u, 2u, 0u})
+                if ((size_t)dd_wg_words(L, K) * 4 + 16 <= kDdLdsBudget) {
+                  nd.fold_fast |= (64u << r) | (K << (8 + 4 * r));
+                  worst = std::max(worst, (size_t)dd_wg_words(L, K) * 4 + 16);
+                  break;
+                }
+            }
             // else span-ordered on HBM tables: no LDS
           }
           // also worth it when a folding has no register form at all: its folder runs the span-ordered form on a
@@ -409,8 +426,8 @@ int nodes_open_impl(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const d
         const bool span_any = span_only || (nd.fold_fast & (16u | 32u)) != 0;
         nd.s_x = (dd_fold_cols(L1) <= DD_WFOLD && !force_wide && !span_only) ? cv.take<float>(((size_t)L1 + 63) * dd_fold_cols(L1) * 64) : nullptr;
         nd.s_y = (dd_fold_cols(L2) <= DD_WFOLD && !force_wide && !span_only) ? cv.take<float>(((size_t)L2 + 63) * dd_fold_cols(L2) * 64) : nullptr;
-        nd.s_xs = span_any ? cv.take<float>((size_t)L1 * ((L1 + 63) & ~63u) + 64) : nullptr;
-        nd.s_ys = span_any ? cv.take<float>((size_t)L2 * ((L2 + 63) & ~63u) + 64) : nullptr;
+        nd.s_xs = (span_any || (nd.fold_fast & 64u)) ? cv.take<float>((size_t)L1 * ((L1 + 63) & ~63u) + 64) : nullptr;
+        nd.s_ys = (span_any || (nd.fold_fast & 128u)) ? cv.take<float>((size_t)L2 * ((L2 + 63) & ~63u) + 64) : nullptr;
       }
       nd.env = cv.take<uint32_t>(2 * ((size_t)L1 + 1));
       nd.env4 = cv.take<uint32_t>(2 * ((size_t)L1 + 130));
@@ -643,6 +660,11 @@ int nodes_result(dafs_hip_ctx* c, uint32_t handle, dafs_node_output* out, bool s
   if (out->z) memcpy(out->z, at(nd.z), (size_t)nd.L1 * 4);
   memcpy(&score, at(nd.score), 4);
   memcpy(info, at(nd.info), sizeof info);
+  if (stamps && nd.fold_fast & (64u | 128u)) {
+    uint32_t sy[8] = {0};
+    if (!hip_check(hipMemcpy(sy, nd.sync, sizeof sy, hipMemcpyDeviceToHost)))
+      fprintf(stderr, "dd node L1=%u L2=%u folders (workgroup form) | us: x-dp %.0f y-dp %.0f tracebacks %.0f\n", nd.L1, nd.L2, sy[5] / 100.0, sy[6] / 100.0, sy[7] / 100.0);
+  }
   if (stamps)
     fprintf(stderr, "dd node L1=%u L2=%u n=%u+%u ncbp=%u iters=%u slow-xy=%u+%u | us: x-dp %.0f x-traceback %.0f wait %.0f cbp %.0f update %.0f tail %.0f | y %.0f z %.0f flags %x\n", nd.L1,
             nd.L2, nd.n1, nd.n2, info[0], info[1], info[4], info[5], info[8] / 100.0, info[9] / 100.0, info[10] / 100.0, info[11] / 100.0, info[12] / 100.0,

@@ -56,7 +56,8 @@ struct dd_node {
   // split mode: the two folding DPs of this node run on workgroups of their own (blockIdx.y = 1, 2) next to
   // the leader (blockIdx.y = 0, alignment DP + constraints + updates); sync[0] go / exit, [1] x done, [2] y done,
   // [3] [4] the folding scores.  fold_fast: bit 0 / 1 the fast form of x / y fits the folder's LDS, bit 2 / 3 the same with the
-  // codes in HBM, bit 4 / 5 the span form fits it (preferred).
+  // codes in HBM, bit 4 / 5 the span form fits it (preferred), bit 6 / 7 no register form but the workgroup form fits
+  // (nuss_wg_span; needs s_xs / s_ys) with K = bits 8..11 / 12..15 candidates per column in LDS.
   uint32_t* sync;
   uint32_t split, fold_fast;
 };
@@ -105,6 +106,9 @@ static inline __host__ __device__ uint32_t dd_ring_words(uint32_t L) {
 #define DD_SPAN_LMAX 256  // four row slots per lane
 static inline __host__ __device__ uint32_t dd_span_nib_words(uint32_t L) { return (uint32_t)((((size_t)L * (L + 1) / 2 + 7) / 8 + 3) & ~(size_t)3); }
 static inline __host__ __device__ uint32_t dd_span_tri_words(uint32_t L) { return (uint32_t)(((size_t)L * (L + 1) / 2 + 3) & ~(size_t)3); }
+// workgroup form of the folding DP beyond the register forms (nuss_wg_span): three rolling rows of dp values, the candidate
+// counters, and the first K candidates (key, value) of every column
+static inline __host__ __device__ uint32_t dd_wg_words(uint32_t L, uint32_t K) { return (4 + 2 * K) * ((L + 3) & ~3u); }
 static inline __host__ __device__ uint32_t dd_span_words(uint32_t L) { return dd_span_nib_words(L) + dd_span_tri_words(L) + 2 * DD_CAP * (L + 1) + DD_CAP * L; }
 // packed traceback table of the alignment DP: two bits per cell, rows padded to whole 32-bit words (16 cells), so that the
 // bit position of a lane's cells within their word is the same in every row

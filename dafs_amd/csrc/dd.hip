@@ -113,6 +113,122 @@ __device__ void nuss_pair_dp(uint32_t LA, const float* pA, const float* qA, floa
 }
 
 // ------------------------------------------------------------------------------------------
+// The workgroup form of the folding DP for alignments beyond the register forms (more than DD_WFOLD columns per lane, i.e.
+// more than 1024 columns), nussinov.cpp:207-298 again.  Span-ordered like nuss_pair_dp, but nothing that the next span
+// waits for crosses global memory unless a column has candidates:
+//   * a cell's three neighbours dp[i+1][j], dp[i][j-1], dp[i+1][j-1] are the two previous spans: three rolling rows in LDS;
+//   * its score comes from the by-span copy S[(j-i)*Lp + i] (dd_fill_scores, kept current by the multiplier updates), one
+//     coalesced load per span, fetched a span ahead for the first cells of every thread;
+//   * the candidate counters and the first K candidates {k, dp[k+1][j-1] + s_kj} of every column sit in LDS, later ones in the
+//     global lists of nuss_ws; the bifurcation terms dp[i][k-1] are the only gathers from the table, issued together for the
+//     four cells a thread handles at a time;
+//   * dp and the traceback codes are written by span, D[(j-i)*L + i] (the arrays of nuss_ws, re-indexed): coalesced stores that
+//     nobody waits for -- a bifurcation reads dp[i][k-1] with k <= j-3, a cell written at least four barriers earlier.
+// Same cells, same comparisons in the same order as nuss_cell, so the same table, codes and structure.
+template <int K>
+__device__ float nuss_wg_span(uint32_t L, const float* __restrict__ S, const nuss_ws& ws, float* lds) {
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t Lr = (L + 3) & ~3u, Lp = (L + 63) & ~63u;
+  float* buf = lds;
+  uint32_t* cc = (uint32_t*)(buf + 3 * Lr);
+  uint32_t* hk = cc + Lr;
+  float* hv = (float*)(hk + (K ? K : 1) * Lr);
+  float* __restrict__ D = ws.dp;
+  uint32_t* __restrict__ T = ws.tr;
+  for (uint32_t i = tid; i < L; i += nt) {
+    buf[i] = 0.0f; buf[Lr + i] = 0.0f; buf[2 * Lr + i] = 0.0f; cc[i] = 0;
+    D[i] = 0.0f; T[i] = 0;                                  // span 0
+    if (i + 1 < L) { D[(size_t)L + i] = 0.0f; T[(size_t)L + i] = 0; }  // span 1: neither neighbour test of nuss_cell holds
+  }
+  constexpr int U = 4;  // cells of a thread whose loads are in flight together
+  float s_ahead[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) { const uint32_t i = tid + u * nt; s_ahead[u] = (2 < L && i < L - 2) ? S[(size_t)2 * Lp + i] : 0.0f; }
+  __syncthreads();
+  for (uint32_t l = 2; l < L; ++l) {
+    const float* p1 = buf + ((l - 1) % 3) * Lr;
+    const float* p2 = buf + ((l - 2) % 3) * Lr;
+    float* cur = buf + (l % 3) * Lr;
+    const uint32_t ncell = L - l;
+    for (uint32_t base = 0; base < ncell; base += U * nt) {
+      float sc[U], g[U][K ? K : 1], hvx[U][K ? K : 1];
+      uint32_t kk[U][K ? K : 1], n[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {  // everything a cell reads from memory
+        const uint32_t i = base + u * nt + tid, j = i + l;
+        n[u] = 0;
+        sc[u] = 0.0f;
+        if (i < ncell) {
+          sc[u] = base == 0 ? s_ahead[u] : S[(size_t)l * Lp + i];
+          n[u] = cc[j];
+#pragma unroll
+          for (int x = 0; x < K; ++x)
+            if ((uint32_t)x < n[u]) {
+              kk[u][x] = hk[x * Lr + j];
+              hvx[u][x] = hv[x * Lr + j];
+              g[u][x] = D[(size_t)(kk[u][x] - 1 - i) * L + i];
+            }
+        }
+      }
+      if (base == 0 && l + 1 < L) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const uint32_t i = tid + u * nt; s_ahead[u] = i < ncell - 1 ? S[(size_t)(l + 1) * Lp + i] : 0.0f; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t i = base + u * nt + tid, j = i + l;
+        if (i >= ncell) continue;
+        float v = p1[i + 1];
+        uint32_t t = 1;
+        { const float b = p1[i]; if (v < b) { v = b; t = 2; } }
+        if (sc[u] > 0.0f) {  // S holds 0 where j - i < 3 (the reference's span test)
+          const float c = p2[i + 1] + sc[u];
+          if (n[u] < (uint32_t)K) { hk[n[u] * Lr + j] = i; hv[n[u] * Lr + j] = c; }
+          else { ws.ck[(size_t)j * L + n[u]] = i; ws.cv[(size_t)j * L + n[u]] = c; }
+          cc[j] = n[u] + 1;
+          if (v < c) { v = c; t = 3; }
+        }
+#pragma unroll
+        for (int x = 0; x < K; ++x)
+          if ((uint32_t)x < n[u]) { const float c = g[u][x] + hvx[u][x]; if (v < c) { v = c; t = kk[u][x] - i + 3; } }
+        for (uint32_t x = K; x < n[u]; ++x) {
+          const uint32_t k = ws.ck[(size_t)j * L + x];
+          const float c = D[(size_t)(k - 1 - i) * L + i] + ws.cv[(size_t)j * L + x];
+          if (v < c) { v = c; t = k - i + 3; }
+        }
+        cur[i] = v;
+        D[(size_t)l * L + i] = v;
+        T[(size_t)l * L + i] = t;
+      }
+    }
+    __syncthreads();
+  }
+  return buf[((L - 1) % 3) * Lr];
+}
+
+// nuss_traceback over the by-span codes of nuss_wg_span
+__device__ void nuss_traceback_span(uint32_t L, const uint32_t* __restrict__ T, uint32_t* ss, uint32_t* stack) {
+  uint32_t sp = 0;
+  stack[0] = 0; stack[1] = L - 1; sp = 1;
+  uint32_t guard = 4 * L + 8;
+  while (sp && guard--) {
+    --sp;
+    const uint32_t i = stack[2 * sp], j = stack[2 * sp + 1];
+    const uint32_t t = T[(size_t)(j - i) * L + i];
+    if (t == 0) continue;
+    if (t == 1) { stack[2 * sp] = i + 1; stack[2 * sp + 1] = j; ++sp; }
+    else if (t == 2) { stack[2 * sp] = i; stack[2 * sp + 1] = j - 1; ++sp; }
+    else if (t == 3) { ss[i] = j; stack[2 * sp] = i + 1; stack[2 * sp + 1] = j - 1; ++sp; }
+    else {
+      const uint32_t k = i + t - 3;
+      stack[2 * sp] = i; stack[2 * sp + 1] = k - 1; ++sp;
+      ss[k] = j;
+      stack[2 * sp] = k + 1; stack[2 * sp + 1] = j - 1; ++sp;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // SparseNeedlemanWunsch
 // ------------------------------------------------------------------------------------------
 // initialize (needleman_wunsch.cpp:198-253); fa/la = scratch of L1+1 uint32 each
@@ -1868,10 +1984,25 @@ __device__ __forceinline__ void dd_folder(const dd_node& nd, const dd_params& pr
       const nuss_ws none = {nullptr, nullptr, nullptr, nullptr, nullptr};
       const float wf = prm.w * 2 * (isx ? nd.n1 : nd.n2) / (nd.n1 + nd.n2);  // dafs.cpp:1091-1092, as in k_dd_solve
       for (uint32_t i = tid; i < L; i += nt) ss[i] = DD_NONE;  // a register-form traceback cut short may have left marks
+      if (nd.fold_fast & (isx ? 64u : 128u)) {
+        // beyond the register forms: the workgroup form (rolling rows and candidate heads in LDS, tables by span)
+        float* lds = (float*)(((uintptr_t)s_dd + 15) & ~(uintptr_t)15);
+        const uint32_t K = (nd.fold_fast >> (isx ? 8 : 12)) & 15u;
+        const float* Ss = isx ? nd.s_xs : nd.s_ys;
+        const unsigned long long tf0 = prm.stamps ? wall_clock64() : 0ull;
+        const float sc = K == 4 ? nuss_wg_span<4>(L, Ss, ws, lds) : K == 2 ? nuss_wg_span<2>(L, Ss, ws, lds) : nuss_wg_span<0>(L, Ss, ws, lds);
+        if (tid == 0) {
+          const unsigned long long tf1 = prm.stamps ? wall_clock64() : 0ull;
+          nuss_traceback_span(L, ws.tr, ss, (uint32_t*)lds);  // the rolling rows are free again: 2(L+2) words of stack
+          s_fscore = sc;
+          if (prm.stamps) { nd.sync[isx ? 5 : 6] += (uint32_t)(tf1 - tf0); nd.sync[7] += (uint32_t)(wall_clock64() - tf1); }  // DP of x / y, tracebacks of both
+        }
+      } else {
       nuss_pair_dp(L, isx ? nd.p_x : nd.p_y, isx ? nd.q_x : nd.q_y, wf, ws, 0, nullptr, nullptr, 0.0f, none, prm.th_s);
       if (tid == 0) {
         nuss_traceback(L, ws, ss, ws.ck);  // the candidate-key array is free again: reuse it as the stack
         s_fscore = ws.dp[L - 1];
+      }
       }
     }
     __syncthreads();

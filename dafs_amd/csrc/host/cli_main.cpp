@@ -11,6 +11,16 @@
 //   -s Boltzmann / -s Vienna and the RNAalifold term need ViennaRNA arithmetic: not available.
 //      The default fold model here is CONTRAfold; asking for the others is an error.
 //   --fold-decoder IPknot / --ipknot / -m 0 need an ILP solver: not available.
+// One addition: --devices a,b,... runs phase 1 (:1787-1827) as one process per listed GPU (dafs_hip_phase1_sharded, the
+// shards all-gathered by RCCL); the processes are forked before anything touches a GPU, and the first one goes on alone.
+#include <dlfcn.h>
+#include <pthread.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <sys/prctl.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +33,12 @@
 #include <string>
 #include <system_error>
 #include <vector>
+
+#ifndef __HIP_PLATFORM_AMD__
+#define __HIP_PLATFORM_AMD__ 1
+#endif
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl is loaded when --devices asks for it (dlopen)
 
 #include "../../../include/dafs_hip.h"
 #include "types.h"
@@ -52,6 +68,7 @@ struct Options {
   std::vector<float> fold_th{0.2f}, fold_th1;
   bool no_alifold = false, ipknot = false, bp_update = false, bp_update1 = false;
   int device = 0;
+  std::vector<int> devices;  // --devices: one process per entry for phase 1
   std::string input;
 };
 
@@ -67,6 +84,8 @@ const char* kHelp =
     "  -f, --fourway-pct arg Weight of four-way PCT (default: 0.0)\n"
     "  -v, --verbose arg     The level of verbose outputs (default: 0)\n"
     "      --device N        HIP device index (default: 0)\n"
+    "      --devices A,B,... One process per listed HIP device for the posteriors and the consistency transform\n"
+    "                        (shards exchanged over RCCL); the progressive alignment runs on the first\n"
     "\n Aligning options:\n"
     "  -a, --align-model arg Alignment model (value=CONTRAlign, ProbCons) (default: ProbCons)\n"
     "  -p, --align-pct arg   Weight of PCT for matching probabilities (default: 0.25)\n"
@@ -105,7 +124,7 @@ Options parse(int argc, char** argv) {
       {"fold-decoder", {0, true}}, {"fold-pct", {'q', true}}, {"fold-th", {'t', true}}, {"gamma", {'g', true}},
       {"no-alifold", {0, false}}, {"fold-th1", {'T', true}}, {"gamma1", {'G', true}}, {"ipknot", {0, false}},
       {"bp-update", {0, false}}, {"bp-update1", {0, false}}, {"fold-aux", {0, true}}, {"save-align-aux", {0, true}},
-      {"save-fold-aux", {0, true}}, {"device", {0, true}}, {"input", {0, true}}};
+      {"save-fold-aux", {0, true}}, {"device", {0, true}}, {"devices", {0, true}}, {"input", {0, true}}};
   std::map<char, std::string> shorts;
   for (const auto& kv : spec)
     if (kv.second.first) shorts[kv.second.first] = kv.first;
@@ -159,6 +178,10 @@ Options parse(int argc, char** argv) {
     else if (name == "save-align-aux") o.save_align_aux = value;
     else if (name == "save-fold-aux") o.save_fold_aux = value;
     else if (name == "device") o.device = std::stoi(value);
+    else if (name == "devices") {
+      for (float d : parse_floats(value)) o.devices.push_back((int)d);
+      if (o.devices.empty()) throw std::string("--devices needs at least one device index");
+    }
     else if (name == "input") o.input = value;
   }
   // thresholds, reference src/dafs.cpp:1709-1750
@@ -421,7 +444,161 @@ void save_align_aux(dafs_hip_ctx* ctx, const std::string& file, const std::vecto
   }
 }
 
-int run(const Options& o) {
+// ---------------------------------------------------------------------------------------------
+// --devices: the ranks of phase 1, one process per listed GPU.  The processes are forked before the first GPU call of
+// the program (a process that has initialised the GPU must neither fork nor exec); rank 0 is the original process and
+// the only one that goes on after phase 1.  What the ranks share is one anonymous mapping made before the fork.
+struct RankShared {
+  pthread_barrier_t barrier;
+  ncclUniqueId nccl_id;  // written by rank 0, read by the others after a barrier
+};
+
+volatile sig_atomic_t g_child_count = 0;
+pid_t g_child_pid[64];
+volatile sig_atomic_t g_child_gone[64];
+
+void on_sigchld(int) {  // a rank that fails takes the run down instead of leaving the others in a collective
+  for (int k = 0; k < g_child_count; ++k) {
+    if (g_child_gone[k]) continue;
+    int st = 0;
+    if (waitpid(g_child_pid[k], &st, WNOHANG) != g_child_pid[k]) continue;
+    g_child_gone[k] = 1;
+    if (!(WIFEXITED(st) && WEXITSTATUS(st) == 0)) {
+      static const char msg[] = "dafs: a rank of --devices failed\n";
+      if (write(2, msg, sizeof msg - 1) < 0) {}
+      _exit(EXIT_FAILURE);  // the remaining ranks die with their parent (PR_SET_PDEATHSIG)
+    }
+  }
+}
+
+struct Ranks {
+  uint32_t rank = 0, world = 1;
+  RankShared* shared = nullptr;
+  uint8_t* stage = nullptr;  // host staging area (only when a device is listed more than once)
+  size_t stage_bytes = 0;
+  void* lib = nullptr;
+  ncclComm_t comm = nullptr;
+  decltype(&ncclGetUniqueId) get_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init = nullptr;
+  decltype(&ncclAllGather) all_gather = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclGetErrorString) err_string = nullptr;
+
+  void fork_ranks(const std::vector<int>& devices) {
+    world = (uint32_t)devices.size();
+    if (world > 64) throw std::string("--devices: at most 64 devices");
+    bool repeated = false;
+    for (size_t a = 0; a < devices.size(); ++a)
+      for (size_t b = 0; b < a; ++b) repeated |= devices[a] == devices[b];
+    // RCCL refuses two ranks on one device; such a list (a rehearsal of the multi-process path on a single GPU) exchanges
+    // its shards through a host staging area instead.  Untouched pages of the mapping cost nothing.
+    if (repeated) stage_bytes = (size_t)sysconf(_SC_PHYS_PAGES) * (size_t)sysconf(_SC_PAGE_SIZE) / 4;
+    const size_t head = 4096;
+    static_assert(sizeof(RankShared) <= 4096, "the header page");
+    void* m = mmap(nullptr, head + stage_bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (m == MAP_FAILED) throw std::string("--devices: cannot map the shared area");
+    shared = (RankShared*)m;
+    stage = (uint8_t*)m + head;
+    pthread_barrierattr_t at;
+    pthread_barrierattr_init(&at);
+    pthread_barrierattr_setpshared(&at, PTHREAD_PROCESS_SHARED);
+    pthread_barrier_init(&shared->barrier, &at, world);
+    std::cout.flush();
+    std::cerr.flush();
+    const pid_t parent = getpid();
+    for (uint32_t r = 1; r < world; ++r) {
+      const pid_t pid = fork();
+      if (pid < 0) throw std::string("--devices: fork failed");
+      if (pid == 0) {
+        prctl(PR_SET_PDEATHSIG, SIGKILL);
+        if (getppid() != parent) _exit(EXIT_FAILURE);  // the parent died before the prctl
+        rank = r;
+        g_child_count = 0;
+        return;
+      }
+      g_child_pid[r - 1] = pid;
+      g_child_gone[r - 1] = 0;
+      g_child_count = (sig_atomic_t)r;
+    }
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_handler = on_sigchld;
+    sa.sa_flags = SA_RESTART | SA_NOCLDSTOP;
+    sigaction(SIGCHLD, &sa, nullptr);
+    on_sigchld(0);  // a rank that died before the handler was in place
+  }
+
+  void barrier() { if (world > 1) pthread_barrier_wait(&shared->barrier); }
+
+  void connect() {  // after dafs_hip_create: the communicator belongs to the context's device
+    if (stage_bytes) return;
+    lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) throw std::string("--devices: cannot load librccl.so.1: ") + dlerror();
+    get_id = (decltype(get_id))dlsym(lib, "ncclGetUniqueId");
+    comm_init = (decltype(comm_init))dlsym(lib, "ncclCommInitRank");
+    all_gather = (decltype(all_gather))dlsym(lib, "ncclAllGather");
+    comm_destroy = (decltype(comm_destroy))dlsym(lib, "ncclCommDestroy");
+    err_string = (decltype(err_string))dlsym(lib, "ncclGetErrorString");
+    if (!get_id || !comm_init || !all_gather || !comm_destroy || !err_string) throw std::string("--devices: librccl.so.1 lacks an entry point");
+    // RCCL announces itself on stdout when the communicator is made (version, host, library path): this program's
+    // stdout is its result, so that goes to stderr
+    std::cout.flush();
+    fflush(stdout);
+    const int keep = dup(1);
+    if (keep >= 0) dup2(2, 1);
+    ncclResult_t r0 = ncclSuccess, r1 = ncclSuccess;
+    if (rank == 0) r0 = get_id(&shared->nccl_id);
+    barrier();
+    if (r0 == ncclSuccess) r1 = comm_init(&comm, (int)world, shared->nccl_id, (int)rank);
+    fflush(stdout);
+    if (keep >= 0) { dup2(keep, 1); close(keep); }
+    nccl(r0);
+    nccl(r1);
+  }
+  void disconnect() {
+    if (comm) { comm_destroy(comm); comm = nullptr; }
+  }
+  void nccl(ncclResult_t r) {
+    if (r != ncclSuccess) throw std::string("RCCL: ") + err_string(r);
+  }
+  void wait_ranks() {  // rank 0, at the end: every rank has left without an error
+    sigset_t block, old;
+    sigemptyset(&block);
+    sigaddset(&block, SIGCHLD);
+    sigprocmask(SIG_BLOCK, &block, &old);
+    bool bad = false;
+    for (int k = 0; k < g_child_count; ++k) {
+      if (g_child_gone[k]) continue;
+      int st = 0;
+      if (waitpid(g_child_pid[k], &st, 0) == g_child_pid[k]) bad |= !(WIFEXITED(st) && WEXITSTATUS(st) == 0);
+      g_child_gone[k] = 1;
+    }
+    sigprocmask(SIG_SETMASK, &old, nullptr);
+    if (bad) throw std::string("a rank of --devices failed");
+  }
+};
+
+// dafs_allgather_fn: ncclAllGather on the stream the library names; between two ranks of one device, host staging
+int rank_allgather(void* user, const void* send, void* recv, size_t bytes, void* stream) {
+  Ranks* rk = (Ranks*)user;
+  if (rk->comm) {
+    const ncclResult_t r = rk->all_gather(send, recv, bytes, ncclChar, rk->comm, (hipStream_t)stream);
+    if (r != ncclSuccess) std::cerr << "RCCL: " << rk->err_string(r) << std::endl;
+    return r == ncclSuccess ? 0 : 1;
+  }
+  if (bytes * rk->world > rk->stage_bytes) {
+    std::cerr << "--devices: the host staging area is too small for " << bytes << " bytes per rank" << std::endl;
+    return 1;
+  }
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 1;
+  if (hipMemcpy(rk->stage + (size_t)rk->rank * bytes, send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  rk->barrier();
+  if (hipMemcpy(recv, rk->stage, (size_t)rk->world * bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
+  rk->barrier();  // nobody overwrites the area before everybody has read it
+  return 0;
+}
+
+int run(const Options& o, Ranks& rk) {
   // ---- option checks mirroring parse_options (:1683-1763)
   int align_model;
   if (o.align_model == "ProbCons") align_model = DAFS_ALIGN_PROBCONS;
@@ -435,6 +612,8 @@ int run(const Options& o) {
   if (o.fold_decoder != "Nussinov" || o.ipknot) throw "Folding decoder IPknot needs an ILP solver, which this build does not contain";
   if (o.max_iter <= 0) throw "-m 0 (exact ILP) needs an ILP solver, which this build does not contain";
   if ((o.bp_update || o.bp_update1) && !o.fold_aux.empty()) throw "--bp-update / --bp-update1 need a folding model (-s CONTRAfold), not --fold-aux";
+  if (!o.devices.empty() && (!o.fold_aux.empty() || !o.align_aux.empty() || o.fourway != 0.0f))
+    throw std::string("--devices shards the posterior models and the consistency transform; --fold-aux, --align-aux and -f run on one device (--device)");
   if (o.verbose >= 1) {
     if (!o.no_alifold) std::cerr << "note: RNAalifold is not available in this build; running as with --no-alifold" << std::endl;
     if (!o.fold_model_given && o.fold_aux.empty()) std::cerr << "note: default folding model is CONTRAfold in this build" << std::endl;
@@ -446,7 +625,7 @@ int run(const Options& o) {
   if (N == 0) throw "no sequences in the input";
 
   dafs_hip_ctx* ctx = nullptr;
-  check(dafs_hip_create(o.device, &ctx));
+  check(dafs_hip_create(o.devices.empty() ? o.device : o.devices[rk.rank], &ctx));
   struct Guard { dafs_hip_ctx* c; ~Guard() { dafs_hip_destroy(c); } } guard{ctx};
 
   std::vector<const char*> seqs(N);
@@ -456,8 +635,11 @@ int run(const Options& o) {
 
   // base-pairing probabilities (:1787).  The device folding is only started here: it keeps one workgroup per
   // sequence busy, and the alignment posteriors and the matching-probability transform run beside it.
+  const bool sharded = !o.devices.empty() && N > 1;
+  if (!sharded && rk.rank != 0) return 0;  // a single sequence: nothing to share
   bool folding = false;
-  if (!o.fold_aux.empty()) {
+  if (sharded) {
+  } else if (!o.fold_aux.empty()) {
     std::vector<BP> bp;
     load_fold_aux(o.fold_aux, fa, bp);
     upload_bp(ctx, bp);
@@ -473,7 +655,18 @@ int run(const Options& o) {
 
   std::vector<node_t> tree(1, std::make_pair(0.0f, std::make_pair(-1u, -1u)));
   if (N == 1) finish_folding();
-  if (N > 1) {
+  if (sharded) {
+    // phase 1 (:1787-1827) on rk.world ranks: every rank ends with the complete stores, rank 0 goes on alone
+    rk.connect();
+    check(dafs_hip_phase1_sharded(ctx, rk.rank, rk.world, align_model, o.align_th, o.align_pct, o.fold_pct, DAFS_FOLD_CONTRAFOLD, kCutoff, rank_allgather, &rk));
+    rk.disconnect();
+    if (rk.rank != 0) return 0;
+    if (!o.save_fold_aux.empty()) save_fold_aux(ctx, o.save_fold_aux, fa);
+    if (!o.save_align_aux.empty()) save_align_aux(ctx, o.save_align_aux, fa);
+    std::vector<float> sim((size_t)N * N);
+    check(dafs_hip_get_sim(ctx, sim.data()));
+    tree = build_tree(sim, N);
+  } else if (N > 1) {
     // matching probabilities, transposes, similarities (:1796-1819), PCTs (:1822-1827), tree (:1830)
     if (!o.align_aux.empty()) load_align_aux(ctx, o.align_aux, fa);
     else check(dafs_hip_align_posteriors(ctx, align_model, o.align_th, 0, 0));
@@ -639,7 +832,12 @@ int run(const Options& o) {
 
 int main(int argc, char* argv[]) {
   try {
-    return run(parse(argc, argv));
+    const Options o = parse(argc, argv);
+    Ranks rk;
+    if (!o.devices.empty()) rk.fork_ranks(o.devices);  // before the first GPU call
+    const int rc = run(o, rk);
+    if (rk.rank == 0) rk.wait_ranks();
+    return rc;
   } catch (const char* str) {
     std::cerr << str << std::endl;
   } catch (const std::string& str) {

@@ -35,7 +35,8 @@ enum {
   DAFS_HIP_ENOMEM = -3,    /* device or host allocation failed */
   DAFS_HIP_ETOOLONG = -4,  /* sequence longer than the kernels support */
   DAFS_HIP_EOVERFLOW = -5, /* sparse output pool too small (retry with a larger pool) */
-  DAFS_HIP_ELAUNCH = -6    /* kernel launch / execution failure */
+  DAFS_HIP_ELAUNCH = -6,   /* kernel launch / execution failure */
+  DAFS_HIP_ECOMM = -7      /* the caller's collective (dafs_allgather_fn) reported a failure */
 };
 const char* dafs_hip_strerror(int code);
 /* last HIP runtime error text seen by this thread (diagnostics) */
@@ -369,6 +370,23 @@ int dafs_hip_mp_install_dev(dafs_hip_ctx* ctx, int relaxed, const uint32_t* nnz,
 int dafs_hip_bp_export_dev(dafs_hip_ctx* ctx, uint32_t* rowptr, uint32_t* col, float* val, uint64_t cap_entries, uint64_t* n_rowptr, uint64_t* n_entries);
 int dafs_hip_set_bp_dev(dafs_hip_ctx* ctx, uint32_t nblocks, const uint32_t* seq_of_block, const uint32_t* rowptr, const uint32_t* col, const float* val,
                         uint64_t n_entries);
+
+/* ---- phase 1 of DAFS::run on one rank of a multi-GPU run (src/dafs.cpp:1787-1827) ----
+ * One process per GPU; every rank has called dafs_hip_set_sequences with all N sequences.  Rank r folds the sequences
+ * x = r (mod world) (independent per sequence, src/fold.cpp:66-67), computes the pair posteriors and similarity scores of
+ * the r-th contiguous range of the row-major pair enumeration (dafs_hip_pair_range; independent per pair,
+ * src/align.cpp:46-50) and relax_matching_probability's output pairs of the same range (src/dafs.cpp:265-315); after each of
+ * the three pieces the shards are packed on the device, all-gathered by `allgather` and installed, so that on return the
+ * context is in the state a single-GPU phase 1 (fold_posteriors, align_posteriors, consistency) leaves it in, bit for
+ * bit, on every rank.  The base-pairing transform is replicated.  Not for the aux-file inputs or the four-way transform.
+ *
+ * dafs_allgather_fn: gather `bytes` bytes from every rank (send, device memory) into recv (device memory, world * bytes,
+ * rank order) -- ncclAllGather's contract.  The collective may be enqueued on hip_stream (a hipStream_t of the context's
+ * device); the library waits for that stream before it reads recv.  Non-zero return = failure (DAFS_HIP_ECOMM). */
+typedef int (*dafs_allgather_fn)(void* user, const void* send, void* recv, size_t bytes, void* hip_stream);
+void dafs_hip_pair_range(uint64_t npairs, uint32_t world, uint32_t rank, uint64_t* begin, uint64_t* end);
+int dafs_hip_phase1_sharded(dafs_hip_ctx* ctx, uint32_t rank, uint32_t world, int align_model, float th_a, float w_pct_a, float w_pct_s,
+                            int fold_model, float fold_th, dafs_allgather_fn allgather, void* user);
 
 /* ---- measurement aid: device time per kernel (bench.py's "stages") ----
  * dafs_hip_stage_timing(ctx, 1) makes every kernel launch of the library record a pair of HIP events on its stream

@@ -176,6 +176,42 @@ def test_errors_follow_the_reference_convention(tmp_path):
         assert rc == 1 and msg in err and out == "", (args, err)   # message on stderr, EXIT_FAILURE (dafs.cpp:1893-1910)
 
 
+def test_devices_flag_shards_phase1_across_processes(tmp_path):
+    """dafs --devices: phase 1 as one process per listed device (dafs_hip_phase1_sharded).  `--devices 0`
+    is one rank whose exchanges go through RCCL (ncclAllGather on a communicator of one); `--devices 0,0,0` is three
+    processes on the one GPU of this box, which RCCL refuses, so their shards travel through the host staging area -- the
+    same library path, the same process structure.  Every variant must print what the single-process run prints, and the
+    aux files written from the gathered stores must be the single-process ones byte for byte."""
+    path = os.path.join(G, "RF00005_0.fa")
+    fa = str(tmp_path / "fam.fa")
+    with open(fa, "w") as f:
+        for n, s in synth.family_set(11, 70, seed=7):
+            f.write(">%s\n%s\n" % (n, s))
+    for inp, flags in ((path, []), (path, ["-a", "CONTRAlign", "-p", "0.3", "-q", "0.2"]), (fa, ["-m", "80"])):
+        rc, want, err = run_cli(*flags, "--save-fold-aux", str(tmp_path / "f0"), "--save-align-aux", str(tmp_path / "a0"), inp)
+        assert rc == 0, err
+        for devs in ("0", "0,0", "0,0,0"):
+            rc, out, err = run_cli(*flags, "--devices", devs, "--save-fold-aux", str(tmp_path / "f1"), "--save-align-aux", str(tmp_path / "a1"), inp)
+            assert rc == 0, (devs, err)
+            assert out == want, devs
+            assert open(str(tmp_path / "f1")).read() == open(str(tmp_path / "f0")).read(), devs
+            assert open(str(tmp_path / "a1")).read() == open(str(tmp_path / "a0")).read(), devs
+    # more ranks than pairs or sequences: the idle ranks still take part in every exchange
+    two = str(tmp_path / "two.fa")
+    with open(two, "w") as f:
+        f.write(">a\nGGGAAACCCUUAGC\n>b\nGGCAAAGCCUAGC\n")
+    rc, want, err = run_cli(two)
+    assert rc == 0, err
+    rc, out, err = run_cli("--devices", "0,0,0", two)
+    assert rc == 0, err
+    assert out == want
+    # what is not sharded says so; a rank that fails takes the run down instead of hanging it
+    rc, out, err = run_cli("--devices", "0,0", "-f", "0.1", path)
+    assert rc != 0 and "--devices" in err
+    rc, out, err = run_cli("--devices", "0,99", path)
+    assert rc != 0
+
+
 def _bits(h):
     return struct.unpack("<f", struct.pack("<I", int(h, 16)))[0]
 

@@ -251,6 +251,29 @@ def test_wide_setup_kernels_equal_oracle(oracle, monkeypatch):
     assert sorted(v[1] for v in got.dd_log.values()) == sorted(int(x) for x in vi)
 
 
+@pytest.mark.parametrize("density", [0.03, 0.3])
+def test_workgroup_folding_form_equals_oracle(oracle, monkeypatch, density):
+    """DAFS_HIP_DD_WG=2 gives every folder of a split node the workgroup form of the folding DP that only foldings beyond
+    1024 columns take (nuss_wg_span: rolling rows and the first candidates of every column in LDS, tables by span); with
+    dense base-pairing inputs the columns hold more candidates than the on-chip heads, so the global list tails run too.
+    Output and iteration log must be the oracle's."""
+    from dafs_amd import pipeline
+    from test_pct_gpu import random_bp
+    recs = synth.family_set(8, 90, seed=25) + synth.random_set(3, 70, seed=26)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    bp = random_bp(seqs, 35, density=density)
+    pl = oracle.pipeline(names, seqs, oracle.params(fold_model=1, t_max=60), bp=bp)
+    pl.phase1(); pl.phase2()
+    want = pl.output()
+    it, vi = pl.dd_log()
+    pl.close()
+    monkeypatch.setenv("DAFS_HIP_DD_WG", "2")
+    got = pipeline.run(names, seqs, bp=bp, t_max=60, skip_uncoupled_folds=False)
+    assert got.output == want
+    assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
+    assert sorted(v[1] for v in got.dd_log.values()) == sorted(int(x) for x in vi)
+
+
 def test_limits_refuse_cleanly_and_context_survives(oracle):
     """what is left of the hard limits: a pair-HMM column sequence beyond 64 lanes x 32 columns, a CONTRAfold sequence
     whose per-position tables outgrow LDS.  Each must come back as ETOOLONG (-4), and the same context must then work."""

@@ -9,6 +9,6 @@ names, seqs = [r[0] for r in recs], [r[1] for r in recs]
 res = pipeline.run(names, seqs, align_model=capi.ALIGN_CONTRALIGN)
 print("seconds", {k: round(v, 3) for k, v in res.seconds.items()}, "rounds", res.levels)
 for k, (dt, nodes) in enumerate(res.rounds):
-    if dt > 0.02:
+    if dt > 0.02 or os.environ.get("DD_ROUNDS_ALL"):
         print("round %3d  %8.1f ms  open %3d  widths %s" % (k, dt * 1e3, len(nodes), sorted(max(a, b) for _, a, b in nodes)[-4:]))
 print("sum of rounds %.2f s" % sum(dt for dt, _ in res.rounds))
