@@ -237,7 +237,7 @@ int plan_check(const dd_node& nd, bool split) {
     return DAFS_HIP_ELAUNCH;
   };
   const void* always[] = {nd.seq1, nd.seq2, nd.rank1, nd.rank2, nd.idx1, nd.idx2, nd.idxoff1, nd.idxoff2, nd.p_x, nd.p_y, nd.p_z, nd.q_x, nd.q_y, nd.q_z,
-                          nd.wx.dp, nd.wx.tr, nd.wx.ck, nd.wx.cv, nd.wx.cc, nd.wy.dp, nd.wy.tr, nd.wy.ck, nd.wy.cv, nd.wy.cc, nd.dp_z, nd.tr_z,
+                          nd.wx.dp, nd.wx.tr, nd.wx.ck, nd.wx.cv, nd.wx.cc, nd.wy.dp, nd.wy.tr, nd.wy.ck, nd.wy.cv, nd.wy.cc, nd.nw_edge, nd.tr_z,
                           nd.trb_x, nd.trb_y, nd.trk_x, nd.trk_y, nd.pz_s, nd.qz_s, nd.env, nd.env4, nd.xmap, nd.ymap, nd.zmap, nd.px_ptr, nd.px_j,
                           nd.py_ptr, nd.py_l, nd.pz_ptr, nd.pz_k, nd.cz_ptr, nd.cz_k, nd.cx_flag, nd.cy_flag, nd.cz_flag, nd.cbp_cnt, nd.cbp, nd.sw,
                           nd.tx, nd.ty, nd.tz, nd.x, nd.y, nd.z, nd.score, nd.info, nd.fstate, nd.sync};
@@ -252,7 +252,7 @@ int plan_check(const dd_node& nd, bool split) {
     if (!(f & 64u) && (f & (2u | 8u)) && regx && !nd.s_x) return bad("register form of the x folding without its sweep-order scores");
     if (!(f & 64u) && (f & (4u | 8u)) && regy && !nd.s_y) return bad("register form of the y folding without its sweep-order scores");
   } else {
-    if (nd.lds_flags & ~(1u | 32u)) return bad("a split leader keeps the alignment DP only");
+    if (nd.lds_flags & ~1u) return bad("a split leader keeps the alignment DP only");
     for (int r = 0; r < 2; ++r) {
       const uint32_t L = r ? nd.L2 : nd.L1;
       const bool reg = r ? regy : regx;
@@ -322,7 +322,7 @@ int nodes_open_impl(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const d
       memset(&nd, 0, sizeof nd);
       const uint32_t L1 = ni.len1, L2 = ni.len2;
       nd.n1 = ni.n1; nd.n2 = ni.n2; nd.L1 = L1; nd.L2 = L2;
-      const size_t XX = (size_t)L1 * L1, YY = (size_t)L2 * L2, ZZ = (size_t)L1 * L2, T = (size_t)(L1 + 1) * (L2 + 1);
+      const size_t XX = (size_t)L1 * L1, YY = (size_t)L2 * L2, ZZ = (size_t)L1 * L2;
       nd.seq1 = cv.take<uint32_t>(ni.n1); nd.seq2 = cv.take<uint32_t>(ni.n2);
       nd.rank1 = cv.take<uint32_t>((size_t)ni.n1 * L1); nd.rank2 = cv.take<uint32_t>((size_t)ni.n2 * L2);
       nd.idx1 = cv.take<uint32_t>(g1[b].idx.size() + 1); nd.idx2 = cv.take<uint32_t>(g2[b].idx.size() + 1);
@@ -341,17 +341,16 @@ int nodes_open_impl(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const d
       fills.push_back({m0, cv.used - m0, 0xFF});
       carve_nuss(cv, L1, nd.wx);
       carve_nuss(cv, L2, nd.wy);
-      nd.dp_z = cv.take<float>(T); nd.tr_z = cv.take<uint8_t>(T);
+      // the alignment DP: columns per lane, and with them the panels of second alignments beyond 64 nw_w - 1 columns
+      nd.nw_w = force_wide ? 1u : dd_nw_cols(L2);
+      const size_t nw_panels = dd_nw_panels(L2, nd.nw_w);
+      nd.nw_edge = cv.take<float>(2 * ((size_t)L1 + 2));
+      nd.tr_z = cv.take<uint8_t>(nw_panels * (L1 + 1) * 512);  // a 64-bit slot per (panel, row, lane)
       nd.trb_x = cv.take<uint8_t>(XX / 2 + L1 + 16); nd.trb_y = cv.take<uint8_t>(YY / 2 + L2 + 16);
       // steps x columns per lane x 64 lanes; only for foldings that have a register form
-      nd.pz_s = cv.take<float>(((size_t)L1 + 63) * ((L2 + 64) / 64) * 64); nd.qz_s = cv.take<float>(((size_t)L1 + 63) * ((L2 + 64) / 64) * 64);
+      nd.pz_s = cv.take<float>(nw_panels * ((size_t)L1 + 63) * nd.nw_w * 64); nd.qz_s = cv.take<float>(nw_panels * ((size_t)L1 + 63) * nd.nw_w * 64);
       nd.trk_x = nd.wx.tr; nd.trk_y = nd.wy.tr;  // the L*L uint32 tables double as bifurcation codes
       {  // LDS plan (mirrors the carving at the top of k_dd_solve / dd_folder)
-        // row buffers of the alignment DP: the previous row and, while they fit, the two input rows (nw_wave)
-        size_t base_z = (size_t)3 * ((L2 + 64) / 64) * 64 * 4;
-        uint32_t lean = 0;
-        if (base_z > kDdLdsBudget - 4096 || force_wide) { base_z /= 3; lean = 32u; }
-        if (base_z > kDdLdsBudget - 4096) return DAFS_HIP_ETOOLONG;  // second alignment beyond ~38 000 columns
         auto nib = [](uint32_t L) { return ((size_t)L * (L + 1) / 2 + 7) / 8; };           // packed traceback codes, words
         // a fast folding DP: codes, the rows in flight (one per active lane), DD_CAP split rows per column
         auto fast = [&](uint32_t L) { return (nib(L) + dd_ring_words(L) + (size_t)DD_CAP * L) * 4; };
@@ -361,8 +360,8 @@ int nodes_open_impl(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const d
         const size_t shared_g = (std::max(dd_ring_words(L1), dd_ring_words(L2)) + (size_t)DD_CAP * Lm) * 4;
         auto fast_g = [&](uint32_t L) { return ((size_t)dd_ring_words(L) + (size_t)DD_CAP * L) * 4; };  // traceback codes in HBM
         auto wide_ok = [](uint32_t L, uint32_t cols) { return dd_fold_cols(L) <= cols; };  // a register form exists for this width
-        size_t used = base_z;
-        nd.lds_flags = lean;
+        size_t used = 0;
+        nd.lds_flags = 0;
         // span form of both foldings side by side (whole dp triangles on chip: up to ~170 + 170 columns); DAFS_HIP_DD_SPAN=0
         // keeps the column-owning forms (tests run both)
         const char* span_env = getenv("DAFS_HIP_DD_SPAN");
@@ -374,7 +373,8 @@ int nodes_open_impl(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const d
         else if (wide_ok(L1, DD_WREG) && wide_ok(L2, DD_WREG) && used + shared <= kDdLdsBudget) { used += shared; nd.lds_flags |= 8u; }      // one region, x then y
         else if (wide_ok(L1, DD_WFOLD) && wide_ok(L2, DD_WFOLD) && used + shared_g <= kDdLdsBudget) { used += shared_g; nd.lds_flags |= 8u | 16u; }  // the same, codes in HBM
         // else: foldings without a register form run span-ordered on HBM tables and need no LDS
-        if (used + need_z <= kDdLdsBudget && !force_wide) { used += need_z; nd.lds_flags |= 1u; }
+        // DAFS_HIP_DD_NWG=1 (tests): no alignment codes in LDS, so that every node takes the register form with its codes in HBM slots
+        if (used + need_z <= kDdLdsBudget && !force_wide && !getenv("DAFS_HIP_DD_NWG") && nd.nw_w <= DD_WNW && L2 < 64u * nd.nw_w) { used += need_z; nd.lds_flags |= 1u; }
         lds[b] = used;
         // split plan: each folding DP on a workgroup of its own.  Worth it when the two do not run side by side
         // in one workgroup; the leader then keeps only the alignment DP (its LDS need is covered by `used`).
@@ -574,7 +574,7 @@ int advance_launch(dafs_hip_ctx* c, const dd_lane& ln, uint32_t n, const uint32_
     const dafs_hip_ctx::dd_open_node& on = c->dd_open[handles[who[b]]];
     if (split && on.split_lds && !on.no_split) {
       nodes[b].split = 1;
-      nodes[b].lds_flags &= (1u | 32u);  // the leader keeps the alignment DP only
+      nodes[b].lds_flags &= 1u;  // the leader keeps the alignment DP only
       lds_max = std::max(lds_max, on.split_lds);
       if (hip_check(hipMemsetAsync(nodes[b].sync, 0, 4, ln.st))) return DAFS_HIP_ELAUNCH;  // clear the exit mark of the last launch
     } else {

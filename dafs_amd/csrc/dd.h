@@ -23,17 +23,18 @@ struct dd_node {
   // averaged posteriors (dafs.cpp:513-607) and Lagrange multipliers
   float *p_x, *p_y, *p_z, *q_x, *q_y, *q_z;
   nuss_ws wx, wy;
-  float* dp_z;        // (L1+1)*(L2+1)
-  uint8_t* tr_z;      // (L1+1)*(L2+1)   traceback codes of the alignment DP (HBM copy, used when it does not fit LDS)
+  float* nw_edge;     // 2*(L1+2): the last column of a panel of the alignment DP, for the next panel (nw_wave_reg)
+  uint8_t* tr_z;      // panels*(L1+1)*512: traceback codes of the alignment DP when they are not packed in LDS -- a 64-bit slot per (panel, row, lane)
+  uint32_t nw_w;      // columns per lane of the alignment DP (dd_nw_cols; DAFS_HIP_DD_WIDE=1 makes it 1): second alignments beyond
+                      // 64*nw_w - 1 columns run as panels of 64*nw_w columns; also the layout of pz_s / qz_s (nw_idx)
   uint8_t *trb_x, *trb_y;   // L(L+1)/2 each: Nussinov traceback codes 0..4 (HBM copies)
   uint32_t *trk_x, *trk_y;  // L*L each: bifurcation code of the cells whose traceback code is 4
   float *s_x, *s_y;         // (L+63)*ceil(L/64)*64 each: pair scores w*(p-th)-q in sweep order of the folding DP; null when the
                             // folding has no register form (more than DD_WFOLD columns per lane)
   float *s_xs, *s_ys;       // L*Lp each (Lp = L rounded up to 64): the same scores stored by span, S[(j-i)*Lp + i], for the span form
                             // (nuss_wave_span); null when no launch of this node can take that form
-  float *pz_s, *qz_s;       // (L1+63)*ceil((L2+1)/64)*64 each: p_z, q_z in sweep order of the alignment DP
+  float *pz_s, *qz_s;       // panels*(L1+63)*nw_w*64 each: p_z, q_z in sweep order of the alignment DP, panel by panel
   uint32_t lds_flags;       // LDS plan: bit 0 packed alignment traceback, bit 1 / bit 2 fast form of the x / y folding DP, bit 3 / 4 shared region / codes in HBM,
-                            // bit 5 alignment wave DP without input row buffers (second alignment too long for them),
                             // bit 6 span form of both folding DPs side by side (whole triangles in LDS; scores from s_xs / s_ys)
   uint32_t* env;      // 2*(L1+1)
   uint32_t* env4;     // 2*(L1+130): the same envelope for the register-resident alignment DP -- {max(first,1), second} of row r at
@@ -86,7 +87,15 @@ int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, 
 int dd_cbp_fill_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, dd_params prm, hipStream_t st);
 #define DD_WREG 8     // widest lane (columns) of the register-resident alignment DP, and of the folding DP with its codes in LDS
 #define DD_WFOLD 16   // widest lane of the register-resident folding DP (codes in HBM beyond DD_WREG)
-#define DD_WNW 16     // widest lane of the register-resident alignment DP (second alignments up to 1023 columns)
+#define DD_WNW 16     // widest lane of the register-resident alignment DP with its codes packed in LDS (second alignments up to 1023 columns)
+#define DD_WNWG 32    // widest lane of the same DP with its codes in HBM, one 64-bit slot per row and lane (up to 2047 columns)
+// columns per lane of the alignment DP, which is also the layout of its sweep-order inputs (nw_skew): beyond DD_WNW the
+// register form exists for multiples of four only
+static inline __host__ __device__ uint32_t dd_nw_cols(uint32_t L2) {
+  const uint32_t W = (L2 + 64) / 64;
+  return W > DD_WNWG ? DD_WNWG : (W > DD_WNW ? (W + 3) & ~3u : W);
+}
+static inline __host__ __device__ uint32_t dd_nw_panels(uint32_t L2, uint32_t W) { return (L2 + 64 * W) / (64 * W); }  // columns 0 .. L2
 #define DD_CAP 4  // candidates per column kept in LDS by the fast folding DP
 // LDS words of the in-flight rows of a fast folding DP: one row of L values per active lane (the lanes own
 // ceil(L/64) columns each, so ceil(L / that) of them are at work).  The previous-row buffers and candidate counters of

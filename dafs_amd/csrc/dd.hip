@@ -873,14 +873,22 @@ __device__ void nuss_traceback_fast(uint32_t L, uint32_t* trb_, const uint8_t* t
 // of M (i-1, k-1), of X (i-1) and of Y (k-1).  The lanes read the next 64 cells along the current direction at once, a
 // ballot finds where the run ends, and the run's entries of `al` are written together: two LDS round trips per run
 // instead of one per cell and a store each.  Row 0 / column 0 are implicit (Y / X); (0,0) ends the walk.
-__device__ bool nw_traceback_wave(uint32_t L1, uint32_t L2, const uint32_t* tr_, uint32_t* al_, int lane) {
+// SLOTS: the table of nw_wave_reg<W, 2> in global memory -- one 64-bit slot per (panel, row, lane), the lane's W cells two bits each.
+template <bool SLOTS>
+__device__ bool nw_traceback_wave(uint32_t L1, uint32_t L2, const uint32_t* tr_, uint32_t* al_, int lane, uint32_t W = 1) {
   DD_LDS const uint32_t* tr = (DD_LDS const uint32_t*)tr_;
+  DD_GLB const unsigned long long* slots = (DD_GLB const unsigned long long*)tr_;
   DD_GLB uint32_t* al = (DD_GLB uint32_t*)al_;
   const uint32_t RW = dd_nwtab_row_words(L2);  // words per row of the table
   auto code = [&](int i, int k) -> uint32_t {  // 1 M, 2 X, 3 Y; 0 at (0,0), outside the grid and where the DP left no mark
     if (i < 0 || k < 0 || (i == 0 && k == 0)) return 0u;
     if (i == 0) return 3u;
     if (k == 0) return 2u;
+    if constexpr (SLOTS) {
+      const uint32_t panel = (uint32_t)k / (64u * W), kp = (uint32_t)k - panel * 64u * W;
+      const uint32_t owner = kp / W, c = kp - owner * W;
+      return (uint32_t)(slots[((size_t)panel * (L1 + 1) + (uint32_t)i) * 64 + owner] >> (2 * c)) & 3u;
+    }
     return (tr[(uint32_t)i * RW + ((uint32_t)k >> 4)] >> (((uint32_t)k & 15u) * 2)) & 3u;
   };
   int i = (int)L1, k = (int)L2;
@@ -915,42 +923,57 @@ __device__ bool nw_traceback_wave(uint32_t L1, uint32_t L2, const uint32_t* tr_,
   return i == 0 && k == 0;
 }
 
-template <int W, bool TRL>
-__device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const float* qs_, float th_, const uint32_t* env_, uint8_t* tr_, int lane) {
+// MODE 1: codes two bits per cell in an LDS table whose rows are whole words (OR-ed in; zeroed by the caller); one panel.
+// MODE 2: codes in global memory, one 64-bit slot per (panel, row, lane) holding the lane's W cells (plain stores, nothing to
+// zero).  Second alignments of more than 64 W columns run as PANELS of 64 W columns, one after the other over all the
+// rows: the last column of a panel goes to `edge` (two arrays of L1 + 2 floats, used in turn), where lane 0 of the next panel
+// finds its left neighbours -- dp[i][k-1] for the row it is on, and through it dp[i-1][k-1] one step later.  The inputs are
+// stored panel by panel in sweep order (nw_idx).
+template <int W, int MODE>
+__device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const float* qs_, float th_, const uint32_t* env_, uint8_t* tr_, float* edge_, int lane) {
   // wave-uniform values in scalar registers (see nuss_wave_span)
   const uint32_t L1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L1_), L2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L2_);
   const float th = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(th_)));
-  DD_GLB const float* ps = (DD_GLB const float*)ps_;
-  DD_GLB const float* qs = (DD_GLB const float*)qs_;
   DD_GLB const uint32_t* env = (DD_GLB const uint32_t*)env_;
-  DD_LDS uint32_t* tr_l = (DD_LDS uint32_t*)tr_;  // TRL: two bits per cell (1 M, 2 X, 3 Y), zeroed by the caller
-  DD_GLB uint8_t* tr_g = (DD_GLB uint8_t*)tr_;
-  const uint32_t T = L2 + 1;
+  DD_LDS uint32_t* tr_l = (DD_LDS uint32_t*)tr_;  // MODE 1: two bits per cell (1 M, 2 X, 3 Y), zeroed by the caller
+  DD_GLB float* edge = (DD_GLB float*)edge_;
+  typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+  const uint32_t npanels = MODE == 1 ? 1u : (L2 + 64u * W) / (64u * W);  // columns 0 .. L2
+  const size_t panel_words = ((size_t)L1 + 63) * W * 64;                  // inputs of one panel
+  const bool lane0 = lane == 0;
   float P[W], Pc[W], Qc[W], np[W], nq[W];
+  float score = 0.0f;
+  for (uint32_t panel = 0; panel < npanels; ++panel) {
+    const int kbase = (int)(panel * 64u * W);
+    const bool first = panel == 0;
+    DD_GLB const float* ps = (DD_GLB const float*)ps_ + panel * panel_words;
+    DD_GLB const float* qs = (DD_GLB const float*)qs_ + panel * panel_words;
+    DD_GLB unsigned long long* tr_g = (DD_GLB unsigned long long*)tr_ + (size_t)panel * (L1 + 1) * 64;
+    DD_GLB const float* ein = edge + (panel & 1u ? 0 : (L1 + 2));   // written by the panel before
+    DD_GLB float* eout = edge + (panel & 1u ? (L1 + 2) : 0);
 #pragma unroll
-  for (int c = 0; c < W; ++c) { P[c] = 0.0f; Pc[c] = ps[(size_t)c * 64 + lane]; Qc[c] = qs[(size_t)c * 64 + lane]; np[c] = 0.0f; nq[c] = 0.0f; }
-  float last = 0.0f, leftprev = 0.0f;
-  const int nsteps = (int)L1 + (int)((L2 + W) / W) - 1;  // lanes beyond column L2 have nothing to do
-  uint32_t ef = 1u, es = 0u;
-  if (lane == 0) { ef = env[2]; es = env[3]; }  // row 1
+    for (int c = 0; c < W; ++c) { P[c] = 0.0f; Pc[c] = ps[(size_t)c * 64 + lane]; Qc[c] = qs[(size_t)c * 64 + lane]; np[c] = 0.0f; nq[c] = 0.0f; }
+    float last = 0.0f, leftprev = 0.0f;
+    const uint32_t lanes_on = (L2 - (uint32_t)kbase) / W + 1 < 64u ? (L2 - (uint32_t)kbase) / W + 1 : 64u;  // lanes beyond column L2 have nothing to do
+    const int nsteps = (int)L1 + (int)lanes_on - 1;
+    float e_cur = 0.0f;  // lane 0: dp[row of this step][kbase - 1]
+    if (!first) e_cur = ein[1];
 #pragma unroll
-  for (int c = 0; c < W; ++c) asm volatile("" : "+v"(Pc[c]), "+v"(Qc[c]));  // nothing pending at the loop header (see nuss_wave_reg)
-  asm volatile("" : "+v"(ef), "+v"(es));
-  if constexpr (TRL) {
-    // The form with the packed table in LDS, straight-line: every cell is computed and then replaced by what its place in
-    // the grid says (outside the envelope: lowest(); column 0: 0; rows outside the grid: unchanged), and the codes of the
-    // lane's W cells -- consecutive cells of one row -- go out together, as one 64-bit value shifted to its place.  What a
-    // step needs besides its cells is kept small: env is the padded envelope (dd_node::env4: {max(first,1), second} of row
-    // r at r + 64, empty ranges around the grid: one 8-byte load, no clamping), the table's rows are whole words, so the
-    // lane's shift and word offset never change and its word pointer just moves down a row.
-    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-    const int k0 = lane * W;
-    const bool lane0 = lane == 0;
+    for (int c = 0; c < W; ++c) asm volatile("" : "+v"(Pc[c]), "+v"(Qc[c]));  // nothing pending at the loop header (see nuss_wave_reg)
+    asm volatile("" : "+v"(e_cur));
+    // Straight-line steps: every cell is computed and then replaced by what its place in the grid says (outside the
+    // envelope: lowest(); column 0: 0; rows outside the grid: unchanged), and the codes of the lane's W cells -- consecutive
+    // cells of one row -- go out together.  What a step needs besides its cells is kept small: env is the padded envelope
+    // (dd_node::env4: {max(first,1), second} of row r at r + 64, empty ranges around the grid: one 8-byte load, no
+    // clamping); the LDS table's rows are whole words, so the lane's shift and word offset never change and its word
+    // pointer just moves down a row.
+    const int k0 = kbase + lane * W;
     const uint32_t RW = dd_nwtab_row_words(L2);
     const uint32_t sh = ((uint32_t)k0 & 15u) * 2u;
     int i = 1 - lane;                                                      // row of step 0
     DD_GLB const v2u* envp = (DD_GLB const v2u*)env + (i + 1 + 64);        // envelope of row i + 1
-    DD_LDS uint32_t* word = tr_l + (int)RW * i + (k0 >> 4);                // the lane's cells in row i (never touched while i < 1)
+    DD_LDS uint32_t* word = tr_l + (int)RW * i + (k0 >> 4);                // MODE 1: the lane's cells in row i (never touched while i < 1)
+    DD_GLB unsigned long long* slot = tr_g + (ptrdiff_t)i * 64 + lane;     // MODE 2: the lane's slot of row i
     DD_GLB const float* pnext = ps + (size_t)W * 64 + lane;                // inputs of step 1
     DD_GLB const float* qnext = qs + (size_t)W * 64 + lane;
     int lo = 1, hi = 0;
@@ -960,6 +983,8 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
       // the envelope of the next row first: loads return in order, so the wait for it at the end of the step leaves the
       // prefetch of the next step's inputs in flight
       const v2u ne = *envp;
+      float e_next = 0.0f;
+      if (MODE == 2 && !first) e_next = ein[(uint32_t)(s + 2) <= L1 ? s + 2 : (int)L1];  // lane 0's left neighbour of the next step
       __builtin_amdgcn_sched_barrier(0);
       if (s + 1 < nsteps) {
 #pragma unroll
@@ -967,7 +992,8 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
       }
       __builtin_amdgcn_sched_barrier(0);
       const bool rowv = i >= 1 && i <= (int)L1;
-      const float recv = wave_shr1(last);  // lane 0 owns column 0, which takes nothing from its left
+      float recv = wave_shr1(last);  // lane 0 of the first panel owns column 0, which takes nothing from its left
+      if (MODE == 2 && !first) recv = lane0 ? e_cur : recv;
       float diag = leftprev;
       float left = recv;
       float v = 0.0f;
@@ -985,97 +1011,73 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
         const uint32_t t = m2 ? 3u : (m1 ? 2u : 1u);
         const bool inside = k >= lo && k <= hi;  // empty outside the rows of the grid
         v = inside ? v2 : -FLT_MAX;
-        if (c == 0) v = lane0 ? 0.0f : v;        // column 0
+        if (c == 0) v = (lane0 && first) ? 0.0f : v;  // column 0
         v = rowv ? v : up;                       // rows outside the grid: the cell keeps what it held (row 0 / the last row)
         codes |= (unsigned long long)(inside ? t : 0u) << (2 * c);
         diag = up;
         P[c] = v;
         left = v;
       }
-      if (codes) {
-        const unsigned long long w = codes << sh;
-        __hip_atomic_fetch_or(word, (uint32_t)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((uint32_t)(w >> 32)) __hip_atomic_fetch_or(word + 1, (uint32_t)(w >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if constexpr (MODE == 1) {
+        if (codes) {
+          const unsigned long long w = codes << sh;
+          __hip_atomic_fetch_or(word, (uint32_t)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if ((uint32_t)(w >> 32)) __hip_atomic_fetch_or(word + 1, (uint32_t)(w >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      } else {
+        if (rowv) *slot = codes;  // every slot of the grid is written in every pass: no stale codes
+        if (rowv && lane == 63 && panel + 1 < npanels) eout[i] = v;  // the panel's last column, for the next panel
       }
       leftprev = recv;
       last = v;
       lo = (int)ne.x; hi = (int)ne.y;
-      ++i; ++envp; word += RW; pnext += W * 64; qnext += W * 64;
+      e_cur = e_next;
+      ++i; ++envp; word += RW; slot += 64; pnext += W * 64; qnext += W * 64;
 #pragma unroll
       for (int c = 0; c < W; ++c) { Pc[c] = np[c]; Qc[c] = nq[c]; }
     }
-  } else {
-  for (int s = 0; s < nsteps; ++s) {
-      const int i = s - lane + 1;
-      const bool rowv = i >= 1 && i <= (int)L1;
-      if (s + 1 < nsteps) {
-  #pragma unroll
-        for (int c = 0; c < W; ++c) { np[c] = ps[((size_t)(s + 1) * W + c) * 64 + lane]; nq[c] = qs[((size_t)(s + 1) * W + c) * 64 + lane]; }
-      }
-      const bool nrow = i + 1 >= 1 && i + 1 <= (int)L1;
-      const uint32_t nef = nrow ? env[2 * (i + 1)] : 1u, nes = nrow ? env[2 * (i + 1) + 1] : 0u;
-      const float recv = wave_shr1(last);  // lane 0 owns column 0, which takes nothing from its left
-      float diag = leftprev;
-      float left = recv;
-      float v = 0.0f;
-  #pragma unroll
-      for (int c = 0; c < W; ++c) {
-        const uint32_t k = lane * W + c;
-        const float up = P[c];
-        v = up;
-        if (rowv && k <= L2) {
-          if (k == 0) v = 0.0f;
-          else if (k >= ef && k <= es) {
-            v = diag + Pc[c] - th;
-            v = v + Qc[c];
-            uint32_t t = 1;
-            if (v < up) { v = up; t = 2; }
-            if (v < left) { v = left; t = 3; }
-            if (TRL) {
-              const uint32_t q = (uint32_t)i * T + k;
-              __hip_atomic_fetch_or(&tr_l[q >> 4], t << ((q & 15u) * 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else tr_g[(size_t)i * T + k] = t == 1 ? 'M' : (t == 2 ? 'X' : 'Y');
-          } else v = -FLT_MAX;
-        }
-        diag = up;
-        P[c] = v;
-        left = v;
-      }
-      leftprev = recv;
-      last = v;
-      ef = nef; es = nes;
-  #pragma unroll
-      for (int c = 0; c < W; ++c) { Pc[c] = np[c]; Qc[c] = nq[c]; }
+    if (panel + 1 < npanels) __threadfence_block();  // the edge column is in place before lane 0 of the next panel reads it
+    else {
+      // dp[L1][L2]: what the lane that owns column L2 holds there after its last row (rows beyond L1 leave P untouched)
+      const uint32_t kk = L2 - (uint32_t)kbase;
+#pragma unroll
+      for (int c = 0; c < W; ++c)
+        if ((uint32_t)c == kk % (uint32_t)W) score = P[c];
+      score = __shfl(score, (int)(kk / W));
     }
   }
-  // dp[L1][L2]: what the lane that owns column L2 holds there after its last row (rows beyond L1 leave P untouched)
-  float score = 0.0f;
-#pragma unroll
-  for (int c = 0; c < W; ++c)
-    if ((uint32_t)c == L2 % (uint32_t)W) score = P[c];
-  return __shfl(score, (int)(L2 / W));
+  return score;
 }
 
-template <bool TRL>
-__device__ __noinline__ float nw_wave_fast(uint32_t W, uint32_t L1, uint32_t L2, const float* ps, const float* qs, float th, const uint32_t* env, uint8_t* tr, int lane) {
+template <int MODE>
+__device__ __noinline__ float nw_wave_fast(uint32_t W, uint32_t L1, uint32_t L2, const float* ps, const float* qs, float th, const uint32_t* env, uint8_t* tr, float* edge, int lane) {
   switch (W) {
-    case 1: return nw_wave_reg<1, TRL>(L1, L2, ps, qs, th, env, tr, lane);
-    case 2: return nw_wave_reg<2, TRL>(L1, L2, ps, qs, th, env, tr, lane);
-    case 3: return nw_wave_reg<3, TRL>(L1, L2, ps, qs, th, env, tr, lane);
-    case 4: return nw_wave_reg<4, TRL>(L1, L2, ps, qs, th, env, tr, lane);
-    case 5: return nw_wave_reg<5, TRL>(L1, L2, ps, qs, th, env, tr, lane);
-    case 6: return nw_wave_reg<6, TRL>(L1, L2, ps, qs, th, env, tr, lane);
-    case 7: return nw_wave_reg<7, TRL>(L1, L2, ps, qs, th, env, tr, lane);
-    case 8: return nw_wave_reg<8, TRL>(L1, L2, ps, qs, th, env, tr, lane);
-    case 9: return nw_wave_reg<9, TRL>(L1, L2, ps, qs, th, env, tr, lane);
-    case 10: return nw_wave_reg<10, TRL>(L1, L2, ps, qs, th, env, tr, lane);
-    case 11: return nw_wave_reg<11, TRL>(L1, L2, ps, qs, th, env, tr, lane);
-    case 12: return nw_wave_reg<12, TRL>(L1, L2, ps, qs, th, env, tr, lane);
-    case 13: return nw_wave_reg<13, TRL>(L1, L2, ps, qs, th, env, tr, lane);
-    case 14: return nw_wave_reg<14, TRL>(L1, L2, ps, qs, th, env, tr, lane);
-    case 15: return nw_wave_reg<15, TRL>(L1, L2, ps, qs, th, env, tr, lane);
-    default: return nw_wave_reg<16, TRL>(L1, L2, ps, qs, th, env, tr, lane);  // DD_WNW
+    case 1: return nw_wave_reg<1, MODE>(L1, L2, ps, qs, th, env, tr, edge, lane);
+    case 2: return nw_wave_reg<2, MODE>(L1, L2, ps, qs, th, env, tr, edge, lane);
+    case 3: return nw_wave_reg<3, MODE>(L1, L2, ps, qs, th, env, tr, edge, lane);
+    case 4: return nw_wave_reg<4, MODE>(L1, L2, ps, qs, th, env, tr, edge, lane);
+    case 5: return nw_wave_reg<5, MODE>(L1, L2, ps, qs, th, env, tr, edge, lane);
+    case 6: return nw_wave_reg<6, MODE>(L1, L2, ps, qs, th, env, tr, edge, lane);
+    case 7: return nw_wave_reg<7, MODE>(L1, L2, ps, qs, th, env, tr, edge, lane);
+    case 8: return nw_wave_reg<8, MODE>(L1, L2, ps, qs, th, env, tr, edge, lane);
+    case 9: return nw_wave_reg<9, MODE>(L1, L2, ps, qs, th, env, tr, edge, lane);
+    case 10: return nw_wave_reg<10, MODE>(L1, L2, ps, qs, th, env, tr, edge, lane);
+    case 11: return nw_wave_reg<11, MODE>(L1, L2, ps, qs, th, env, tr, edge, lane);
+    case 12: return nw_wave_reg<12, MODE>(L1, L2, ps, qs, th, env, tr, edge, lane);
+    case 13: return nw_wave_reg<13, MODE>(L1, L2, ps, qs, th, env, tr, edge, lane);
+    case 14: return nw_wave_reg<14, MODE>(L1, L2, ps, qs, th, env, tr, edge, lane);
+    case 15: return nw_wave_reg<15, MODE>(L1, L2, ps, qs, th, env, tr, edge, lane);
+    case 16: return nw_wave_reg<16, MODE>(L1, L2, ps, qs, th, env, tr, edge, lane);  // DD_WNW
   }
+  if constexpr (MODE == 2) {  // beyond DD_WNW: multiples of four up to DD_WNWG (dd_nw_cols)
+    switch (W) {
+      case 20: return nw_wave_reg<20, 2>(L1, L2, ps, qs, th, env, tr, edge, lane);
+      case 24: return nw_wave_reg<24, 2>(L1, L2, ps, qs, th, env, tr, edge, lane);
+      case 28: return nw_wave_reg<28, 2>(L1, L2, ps, qs, th, env, tr, edge, lane);
+      case 32: return nw_wave_reg<32, 2>(L1, L2, ps, qs, th, env, tr, edge, lane);
+    }
+  }
+  return 0.0f;  // unreachable: the caller asks for widths dd_nw_cols produces
 }
 
 // Sweep-order ("skewed") copies of the DP inputs: the value lane t needs at step s for its column c sits
@@ -1084,9 +1086,14 @@ __device__ __forceinline__ size_t nuss_skew(uint32_t L, uint32_t W, uint32_t i, 
   const uint32_t lane = j / W, c = j - lane * W, step = L - 1 - i + lane;
   return ((size_t)step * W + c) * 64 + lane;
 }
-__device__ __forceinline__ size_t nw_skew(uint32_t W, uint32_t i, uint32_t k) {  // i in 1..L1, k in 0..L2
+__device__ __forceinline__ size_t nw_skew(uint32_t W, uint32_t i, uint32_t k) {  // i in 1..L1, k in 0..64W-1 (within a panel)
   const uint32_t lane = k / W, c = k - lane * W, step = i - 1 + lane;
   return ((size_t)step * W + c) * 64 + lane;
+}
+// where input (i, k) of the alignment DP lives: panel k / 64W, then sweep order within the panel
+__device__ __forceinline__ size_t nw_idx(uint32_t L1, uint32_t W, uint32_t i, uint32_t k) {  // i in 1..L1, k in 0..L2
+  const uint32_t panel = k / (64u * W);
+  return (size_t)panel * ((size_t)L1 + 63) * W * 64 + nw_skew(W, i, k - panel * 64u * W);
 }
 // where the score of cell (i, j), j >= i, lives: by span for the span form (nuss_wave_span), else in sweep order
 __device__ __forceinline__ size_t fold_sidx(bool span, uint32_t L, uint32_t W, uint32_t i, uint32_t j) {
@@ -1101,103 +1108,15 @@ __device__ void dd_fill_scores(bool span, uint32_t L, const float* __restrict__ 
     S[fold_sidx(span, L, W, i, j)] = j >= i + 3 ? w * (p[c] - th) - q[c] : 0.0f;  // a pair spans at least three (nussinov.cpp:236 is inside the span loop)
   }
 }
-__device__ void dd_fill_nw(uint32_t L1, uint32_t L2, const float* __restrict__ p, const float* __restrict__ q, float* ps, float* qs) {
-  const uint32_t W = (L2 + 64) / 64;
+__device__ void dd_fill_nw(uint32_t L1, uint32_t L2, uint32_t W, const float* __restrict__ p, const float* __restrict__ q, float* ps, float* qs) {
   for (size_t c = threadIdx.x; c < (size_t)L1 * L2; c += blockDim.x) {
     const uint32_t i = (uint32_t)(c / L2), k = (uint32_t)(c - (size_t)i * L2);
-    const size_t o = nw_skew(W, i + 1, k + 1);
+    const size_t o = nw_idx(L1, W, i + 1, k + 1);
     ps[o] = p[c];
     qs[o] = q[c];
   }
 }
 
-
-// SparseNeedlemanWunsch::decode DP (needleman_wunsch.cpp:276-296) by one wavefront; row i at step
-// i-1+lane.  Cells outside the envelope hold lowest(), row 0 / column 0 hold 0.  tr must have been
-// initialised by nw_init_tr.  Returns dp[L1][L2].
-__device__ float nw_wave(uint32_t L1, uint32_t L2, const float* __restrict__ ps_, const float* __restrict__ qs_, float th,
-                         const uint32_t* __restrict__ env_, uint8_t* tr_, float* P_, float* Pb_, float* Qb_, int lane) {
-  DD_GLB const float* ps = (DD_GLB const float*)ps_;
-  DD_GLB const float* qs = (DD_GLB const float*)qs_;
-  DD_GLB const uint32_t* env = (DD_GLB const uint32_t*)env_;
-  DD_GLB uint8_t* tr = (DD_GLB uint8_t*)tr_;
-  DD_LDS float* P = (DD_LDS float*)P_;
-  DD_LDS float* Pb = (DD_LDS float*)Pb_;
-  DD_LDS float* Qb = (DD_LDS float*)Qb_;
-  const uint32_t W = (L2 + 1 + 63) / 64, T = L2 + 1;
-  const bool buf = Pb_ != nullptr;  // without room for the input row buffers (second alignments beyond ~12 000 columns) the cells read HBM
-  for (uint32_t c = 0; c < W; ++c) {
-    P[c * 64 + lane] = 0.0f;  // row 0
-    if (buf) {
-      Pb[c * 64 + lane] = ps[(size_t)c * 64 + lane];
-      Qb[c * 64 + lane] = qs[(size_t)c * 64 + lane];
-    }
-  }
-  float last = 0.0f, leftprev = 0.0f;
-  const int nsteps = (int)L1 + (int)((L2 + W) / W) - 1;  // lanes beyond column L2 have nothing to do
-  uint32_t ef = 1u, es = 0u;
-  if (lane == 0) { ef = env[2]; es = env[3]; }  // row 1
-  for (int s = 0; s < nsteps; ++s) {
-    const int i = s - lane + 1;
-    const bool rowv = i >= 1 && i <= (int)L1;
-    float np[DD_WMAX], nq[DD_WMAX];
-    const bool nv = buf && s + 1 < nsteps;
-#pragma unroll
-    for (int c = 0; c < DD_WMAX; ++c) {
-      const bool on = nv && (uint32_t)c < W;
-      np[c] = on ? ps[((size_t)(s + 1) * W + c) * 64 + lane] : 0.0f;
-      nq[c] = on ? qs[((size_t)(s + 1) * W + c) * 64 + lane] : 0.0f;
-    }
-    const bool nrow = i + 1 >= 1 && i + 1 <= (int)L1;
-    const uint32_t nef = nrow ? env[2 * (i + 1)] : 1u, nes = nrow ? env[2 * (i + 1) + 1] : 0u;
-    const float recv = __shfl_up(last, 1);
-    float diag = leftprev;  // dp[i-1][k-1]
-    float left = recv;      // dp[i][k-1]
-    float v = 0.0f;
-    for (uint32_t c = 0; c < W; ++c) {
-      const uint32_t k = lane * W + c;
-      const float up = P[c * 64 + lane];  // dp[i-1][k]
-      v = up;  // rows not started yet keep row 0
-      if (rowv && k <= L2) {
-        if (k == 0) v = 0.0f;
-        else if (k >= ef && k <= es) {
-          const size_t o = ((size_t)s * W + c) * 64 + lane;
-          v = diag + (buf ? Pb[c * 64 + lane] : ps[o]) - th;
-          v = v + (buf ? Qb[c * 64 + lane] : qs[o]);
-          uint8_t t = 'M';
-          if (v < up) { v = up; t = 'X'; }
-          if (v < left) { v = left; t = 'Y'; }
-          tr[(size_t)i * T + k] = t;
-        } else v = -FLT_MAX;
-      }
-      diag = up;
-      P[c * 64 + lane] = v;
-      left = v;
-    }
-    leftprev = recv;
-    last = v;
-    ef = nef; es = nes;
-    if (buf) {
-#pragma unroll
-      for (int c = 0; c < DD_WMAX; ++c)
-        if ((uint32_t)c < W) { Pb[c * 64 + lane] = np[c]; Qb[c * 64 + lane] = nq[c]; }
-      for (uint32_t c = DD_WMAX; c < W; ++c) {
-        Pb[c * 64 + lane] = nv ? ps[((size_t)(s + 1) * W + c) * 64 + lane] : 0.0f;
-        Qb[c * 64 + lane] = nv ? qs[((size_t)(s + 1) * W + c) * 64 + lane] : 0.0f;
-      }
-    }
-  }
-  const float score = P[(L2 % W) * 64 + lane];  // dp[L1][L2] in the lane that owns column L2: rows beyond L1 leave P untouched
-  return __shfl(score, (int)(L2 / W));
-}
-
-__device__ void nw_init_tr(uint32_t L1, uint32_t L2, uint8_t* tr) {  // needleman_wunsch.cpp:264-274
-  const uint32_t T = L2 + 1;
-  for (size_t c = threadIdx.x; c < (size_t)(L1 + 1) * T; c += blockDim.x) {
-    const uint32_t i = (uint32_t)(c / T), k = (uint32_t)(c % T);
-    tr[c] = (i == 0 && k == 0) ? ' ' : (k == 0 ? 'X' : (i == 0 ? 'Y' : ' '));
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // standalone decoders (Fold::Decoder / Align::Decoder plugin calls)
@@ -1580,10 +1499,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes,
   if (parts == 1 || part == 1) row_lists(L2, L2, nd.p_y, true, nd.py_ptr, nd.py_l, nd.ymap);
   if (parts == 1 || part == 2) row_lists(L1, L2, nd.p_z, false, nd.pz_ptr, nd.pz_k, nullptr);
   if (parts > 1) {
-    if (part == 3) {  // alignment envelope + table initialisation
-      nw_envelope(L1, L2, nd.p_z, prm.th_a, nd.env, nd.x, nd.z);  // x / z double as scratch here
-      nw_init(L1, L2, nd.dp_z, nd.tr_z);
-    }
+    if (part == 3) nw_envelope(L1, L2, nd.p_z, prm.th_a, nd.env, nd.x, nd.z);  // alignment envelope; x / z double as scratch here
     __shared__ uint32_t s_ticket;
     __threadfence();  // this part's lists, before the arrival
     __syncthreads();
@@ -1627,10 +1543,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_node_lists(const dd_node* nodes,
     }
   }
   atomicAdd(&s_total, mine);
-  if (parts == 1) {  // alignment envelope + table initialisation
-    nw_envelope(L1, L2, nd.p_z, prm.th_a, nd.env, nd.x, nd.z);  // x / z double as scratch here
-    nw_init(L1, L2, nd.dp_z, nd.tr_z);
-  }
+  if (parts == 1) nw_envelope(L1, L2, nd.p_z, prm.th_a, nd.env, nd.x, nd.z);  // alignment envelope; x / z double as scratch here
   __syncthreads();
   if (tid == 0 && ncbp_out) ncbp_out[blockIdx.x] = s_total;  // the host sizes the constraint block from this (one copy per call)
   if (tid == 0) { nd.info[0] = s_total; nd.info[1] = 0; nd.info[2] = 0; nd.info[3] = 0; nd.info[4] = 0; nd.info[5] = 0; nd.info[6] = 0; nd.info[7] = 0; }
@@ -1726,17 +1639,6 @@ __global__ __launch_bounds__(DD_THREADS) void k_lists_scan(const dd_node* nodes)
   if (threadIdx.x == 0) ptr[0] = 0;
   __syncthreads();
   block_scan_inclusive(ptr + 1, R);
-}
-// grid (blocks of cells, node): nw_init (:262-274) over the whole table
-__global__ __launch_bounds__(256) void k_nw_init_wide(const dd_node* nodes) {
-  const dd_node nd = nodes[blockIdx.y];
-  const uint32_t W = nd.L2 + 1;
-  const size_t cells = (size_t)(nd.L1 + 1) * W;
-  for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x) {
-    const uint32_t i = (uint32_t)(c / W), k = (uint32_t)(c % W);
-    nd.dp_z[c] = (i == 0 || k == 0) ? 0.0f : -FLT_MAX;
-    nd.tr_z[c] = (i == 0 && k == 0) ? ' ' : (k == 0 ? 'X' : (i == 0 ? 'Y' : ' '));
-  }
 }
 // the envelope's sequential smoothing passes (needleman_wunsch.cpp:218-243) over first / last columns that are already
 // there (fa = nd.x, la = nd.z): thread 0, on an LDS copy while it fits
@@ -2055,19 +1957,13 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
   // dynamic LDS: previous-row buffers and candidate counters of the three wave DPs, then whichever
   // traceback tables fit (nd.lds_flags, decided by the host): bit 0 alignment, bit 1 x, bit 2 y
   extern __shared__ unsigned char s_dd[];
-  const uint32_t Wx = dd_fold_cols(L1), Wy = dd_fold_cols(L2), Wz = (L2 + 64) / 64;
-  const bool nw_lean = (nd.lds_flags & 32u) != 0;  // no room for the input row buffers of nw_wave
-  float* Pz = (float*)s_dd;
-  float* Pbz = nw_lean ? nullptr : Pz + Wz * 64;
-  float* Qbz = nw_lean ? nullptr : Pbz + Wz * 64;
+  const uint32_t Wx = dd_fold_cols(L1), Wy = dd_fold_cols(L2), Wz = nd.nw_w;
   // previous-row buffers and candidate counters of the HBM-table folding forms: room of their own only when the
   // fold has no on-chip region (otherwise they borrow its ring, see dd_ring_words) and this workgroup folds at all
   const bool fastx = (nd.lds_flags & (2u | 8u)) != 0, fasty = (nd.lds_flags & (4u | 8u)) != 0;
   float *Px = nullptr, *Py = nullptr;
   unsigned char* lds_tail;
-  {
-    lds_tail = (unsigned char*)(Pz + (size_t)(nw_lean ? 1 : 3) * Wz * 64);  // a folding without register form needs no LDS
-  }
+  lds_tail = s_dd;
   // bit 0: packed alignment traceback; bit 1 / bit 2: the fast form of the x / y folding DP
   // (in-flight rows, candidate lists and packed traceback codes)
   const uint32_t nzw = dd_nwtab_words(L1, L2), nxw = (uint32_t)(((size_t)L1 * (L1 + 1) / 2 + 7) / 8),
@@ -2111,7 +2007,6 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     for (uint32_t e = tid; e < dd_span_tri_words(L2); e += nt) triy[e] = 0.0f;
   }
   if (!resume) {
-    if (!(trzp && Wz <= DD_WNW && !nw_lean)) nw_init_tr(L1, L2, trz);  // the byte table in HBM: only for alignments whose codes are not packed in LDS
     // sweep-order inputs of the three DPs, built once; the multiplier updates below keep them current
     if (!(prm.skip_xy && ncbp == 0)) {  // a node that leaves its foldings out (see fold_on below) needs no scores
       if (nd.s_x) dd_fill_scores(false, L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_x);  // only foldings with a register form keep one
@@ -2119,7 +2014,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
       if (nd.s_xs) dd_fill_scores(true, L1, nd.p_x, nd.q_x, w_x, prm.th_s, nd.s_xs);  // the copy the span form reads
       if (nd.s_ys) dd_fill_scores(true, L2, nd.p_y, nd.q_y, w_y, prm.th_s, nd.s_ys);
     }
-    dd_fill_nw(L1, L2, nd.p_z, nd.q_z, nd.pz_s, nd.qz_s);
+    dd_fill_nw(L1, L2, Wz, nd.p_z, nd.q_z, nd.pz_s, nd.qz_s);
     for (uint32_t r = tid; r < L1 + 130; r += nt) {  // the padded envelope (dd_node::env4)
       const bool in = r >= 65 && r <= L1 + 64;        // rows 1 .. L1
       const uint32_t ef = in ? nd.env[2 * (r - 64)] : 1u, es = in ? nd.env[2 * (r - 64) + 1] : 0u;
@@ -2213,12 +2108,14 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     if (wave == 2) {
       float sc;
       const unsigned long long tz0 = prm.stamps ? wall_clock64() : 0ull;
-      if (Wz <= DD_WNW && !nw_lean) sc = trzp ? nw_wave_fast<true>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env4, (uint8_t*)trzp, lane)
-                                   : nw_wave_fast<false>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, trz, lane);
-      else sc = nw_wave(L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env, trz, Pz, Pbz, Qbz, lane);
+      // the register form: codes packed in LDS when the plan has room for them (bit 0; one panel, up to DD_WNW columns per
+      // lane), else in HBM slots (any width: panels of 64 Wz columns)
+      const bool reg_l = trzp && Wz <= DD_WNW && L2 < 64u * Wz;
+      if (reg_l) sc = nw_wave_fast<1>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env4, (uint8_t*)trzp, nullptr, lane);
+      else sc = nw_wave_fast<2>(Wz, L1, L2, nd.pz_s, nd.qz_s, prm.th_a, nd.env4, trz, nd.nw_edge, lane);
       bool ok = true;
-      if (trzp && Wz <= DD_WNW && !nw_lean) { wave_lds_fence(); ok = nw_traceback_wave(L1, L2, trzp, nd.z, lane); }  // by the whole wavefront
-      else if (lane == 0) ok = nw_traceback(L1, L2, trz, nd.z);
+      if (reg_l) { wave_lds_fence(); ok = nw_traceback_wave<false>(L1, L2, trzp, nd.z, lane); }  // by the whole wavefront
+      else { __threadfence_block(); ok = nw_traceback_wave<true>(L1, L2, (const uint32_t*)trz, nd.z, lane, Wz); }
       if (lane == 0) {
         s_score[2] = sc;
         if (!ok) s_bad = 1;
@@ -2350,7 +2247,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
         const float v = nd.q_z[(size_t)i * L2 + kz] - eta * (1 - tc);
         const float qn = (0.0f < v) ? v : 0.0f;
         nd.q_z[(size_t)i * L2 + kz] = qn;
-        nd.qz_s[nw_skew(Wz, i + 1, kz + 1)] = qn;
+        nd.qz_s[nw_idx(L1, Wz, i + 1, kz + 1)] = qn;
       }
       for (uint32_t e = nd.cz_ptr[i]; e < nd.cz_ptr[i + 1]; ++e) {
         const uint32_t kk = nd.cz_k[e];
@@ -2360,7 +2257,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
           const float v = nd.q_z[(size_t)i * L2 + kk] + eta * tc;
           const float qn = (0.0f < v) ? v : 0.0f;
           nd.q_z[(size_t)i * L2 + kk] = qn;
-          nd.qz_s[nw_skew(Wz, i + 1, kk + 1)] = qn;
+          nd.qz_s[nw_idx(L1, Wz, i + 1, kk + 1)] = qn;
         }
       }
     }
@@ -2504,8 +2401,6 @@ int dd_lists_launch(const dd_node* d_nodes, uint32_t nnodes, uint32_t max_len1, 
     STAGE_LAUNCH(ST_NODE_LISTS, st) hipLaunchKernelGGL(k_lists_scan, dim3(nnodes, 3), dim3(DD_THREADS), 0, st, d_nodes);
     if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
     STAGE_LAUNCH(ST_NODE_LISTS, st) hipLaunchKernelGGL(k_lists_rows, rows, dim3(512), 0, st, d_nodes, prm.th_a, 1);
-    if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
-    STAGE_LAUNCH(ST_NODE_LISTS, st) hipLaunchKernelGGL(k_nw_init_wide, dim3(1024, nnodes), dim3(256), 0, st, d_nodes);
     if (hip_check(hipGetLastError())) return DAFS_HIP_ELAUNCH;
     STAGE_LAUNCH(ST_NODE_LISTS, st) hipLaunchKernelGGL(k_node_lists_tail, dim3(nnodes), dim3(DD_THREADS), 0, st, d_nodes, prm, d_ncbp);
     return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;

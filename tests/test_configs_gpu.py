@@ -208,9 +208,10 @@ def _check_arena(res):
 
 # ---------------------------------------------------------------------------------------------- wide forms, limits, arena
 def test_wide_alignment_forms_equal_oracle(oracle):
-    """DAFS_HIP_DD_WIDE=1 pushes every node through the forms only >4096-column alignments reach (foldings span-ordered on
-    HBM tables with no sweep-order copy, alignment wave DP without input row buffers, row pointers searched in HBM, one
-    averaging row per workgroup); the run must still be the oracle's, iteration log included."""
+    """DAFS_HIP_DD_WIDE=1 pushes every node through the forms only very wide alignments reach (foldings span-ordered on
+    HBM tables with no sweep-order copy; the alignment DP in panels -- of 64 columns here, one column per lane, where
+    second alignments beyond 2047 columns take panels of 2048 -- with its codes in HBM slots; row pointers searched in
+    HBM; one averaging row per workgroup); the run must still be the oracle's, iteration log included."""
     from dafs_amd import pipeline
     from test_pct_gpu import random_bp
     recs = synth.family_set(9, 70, seed=5) + synth.random_set(3, 90, seed=6)
@@ -245,6 +246,28 @@ def test_wide_setup_kernels_equal_oracle(oracle, monkeypatch):
     it, vi = pl.dd_log()
     pl.close()
     monkeypatch.setenv("DAFS_HIP_DD_LISTS_WIDE", "1")
+    got = pipeline.run(names, seqs, bp=bp, skip_uncoupled_folds=False)
+    assert got.output == want
+    assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
+    assert sorted(v[1] for v in got.dd_log.values()) == sorted(int(x) for x in vi)
+
+
+def test_alignment_codes_in_hbm_slots_equal_oracle(oracle, monkeypatch):
+    """DAFS_HIP_DD_NWG=1 keeps the alignment DP's traceback codes out of LDS, so every node takes the register form that
+    writes them to HBM, one 64-bit slot per (row, lane) (nw_wave_reg<W, 2>), and the wave traceback that reads them from
+    there -- what second alignments of 1024 to 2047 columns, and narrower ones whose table does not fit LDS, run on.
+    Output and iteration log must be the oracle's."""
+    from dafs_amd import pipeline
+    from test_pct_gpu import random_bp
+    recs = synth.family_set(8, 90, seed=35) + synth.random_set(3, 70, seed=36)
+    names, seqs = [r[0] for r in recs], [r[1] for r in recs]
+    bp = random_bp(seqs, 45, density=0.03)
+    pl = oracle.pipeline(names, seqs, oracle.params(fold_model=1), bp=bp)
+    pl.phase1(); pl.phase2()
+    want = pl.output()
+    it, vi = pl.dd_log()
+    pl.close()
+    monkeypatch.setenv("DAFS_HIP_DD_NWG", "1")
     got = pipeline.run(names, seqs, bp=bp, skip_uncoupled_folds=False)
     assert got.output == want
     assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
