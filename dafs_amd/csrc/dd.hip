@@ -35,6 +35,10 @@
 
 namespace dafs {
 
+// Address-space-qualified views: the wave DPs must compile to ds_* / global_* instructions, not flat_* ones (a flat
+// access counts on both wait counters, so an LDS operand would wait for every global store and load in flight)
+#define DD_LDS __attribute__((address_space(3)))
+#define DD_GLB __attribute__((address_space(1)))
 #define DD_CUTOFF 0.01f  // reference CUTOFF (double 0.01): for float v, v > 0.01 <=> v > 0.01f
 #define DD_NONE 0xFFFFFFFFu
 #define DD_THREADS 512
@@ -126,15 +130,19 @@ __device__ void nuss_pair_dp(uint32_t LA, const float* pA, const float* qA, floa
 //     nobody waits for -- a bifurcation reads dp[i][k-1] with k <= j-3, a cell written at least four barriers earlier.
 // Same cells, same comparisons in the same order as nuss_cell, so the same table, codes and structure.
 template <int K>
-__device__ float nuss_wg_span(uint32_t L, const float* __restrict__ S, const nuss_ws& ws, float* lds) {
+__device__ float nuss_wg_span(uint32_t L, const float* __restrict__ S_, const nuss_ws& ws, float* lds) {
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const uint32_t Lr = (L + 3) & ~3u, Lp = (L + 63) & ~63u;
-  float* buf = lds;
-  uint32_t* cc = (uint32_t*)(buf + 3 * Lr);
-  uint32_t* hk = cc + Lr;
-  float* hv = (float*)(hk + (K ? K : 1) * Lr);
-  float* __restrict__ D = ws.dp;
-  uint32_t* __restrict__ T = ws.tr;
+  // address-space-qualified views (see DD_LDS): a flat access to LDS would wait for every global store in flight
+  DD_LDS float* buf = (DD_LDS float*)lds;
+  DD_LDS uint32_t* cc = (DD_LDS uint32_t*)(buf + 3 * Lr);
+  DD_LDS uint32_t* hk = cc + Lr;
+  DD_LDS float* hv = (DD_LDS float*)(hk + (K ? K : 1) * Lr);
+  DD_GLB const float* S = (DD_GLB const float*)S_;
+  DD_GLB float* D = (DD_GLB float*)ws.dp;
+  DD_GLB uint32_t* T = (DD_GLB uint32_t*)ws.tr;
+  DD_GLB uint32_t* gck = (DD_GLB uint32_t*)ws.ck;
+  DD_GLB float* gcv = (DD_GLB float*)ws.cv;
   for (uint32_t i = tid; i < L; i += nt) {
     buf[i] = 0.0f; buf[Lr + i] = 0.0f; buf[2 * Lr + i] = 0.0f; cc[i] = 0;
     D[i] = 0.0f; T[i] = 0;                                  // span 0
@@ -146,9 +154,9 @@ __device__ float nuss_wg_span(uint32_t L, const float* __restrict__ S, const nus
   for (int u = 0; u < U; ++u) { const uint32_t i = tid + u * nt; s_ahead[u] = (2 < L && i < L - 2) ? S[(size_t)2 * Lp + i] : 0.0f; }
   __syncthreads();
   for (uint32_t l = 2; l < L; ++l) {
-    const float* p1 = buf + ((l - 1) % 3) * Lr;
-    const float* p2 = buf + ((l - 2) % 3) * Lr;
-    float* cur = buf + (l % 3) * Lr;
+    DD_LDS const float* p1 = buf + ((l - 1) % 3) * Lr;
+    DD_LDS const float* p2 = buf + ((l - 2) % 3) * Lr;
+    DD_LDS float* cur = buf + (l % 3) * Lr;
     const uint32_t ncell = L - l;
     for (uint32_t base = 0; base < ncell; base += U * nt) {
       float sc[U], g[U][K ? K : 1], hvx[U][K ? K : 1];
@@ -184,7 +192,7 @@ __device__ float nuss_wg_span(uint32_t L, const float* __restrict__ S, const nus
         if (sc[u] > 0.0f) {  // S holds 0 where j - i < 3 (the reference's span test)
           const float c = p2[i + 1] + sc[u];
           if (n[u] < (uint32_t)K) { hk[n[u] * Lr + j] = i; hv[n[u] * Lr + j] = c; }
-          else { ws.ck[(size_t)j * L + n[u]] = i; ws.cv[(size_t)j * L + n[u]] = c; }
+          else { gck[(size_t)j * L + n[u]] = i; gcv[(size_t)j * L + n[u]] = c; }
           cc[j] = n[u] + 1;
           if (v < c) { v = c; t = 3; }
         }
@@ -192,8 +200,8 @@ __device__ float nuss_wg_span(uint32_t L, const float* __restrict__ S, const nus
         for (int x = 0; x < K; ++x)
           if ((uint32_t)x < n[u]) { const float c = g[u][x] + hvx[u][x]; if (v < c) { v = c; t = kk[u][x] - i + 3; } }
         for (uint32_t x = K; x < n[u]; ++x) {
-          const uint32_t k = ws.ck[(size_t)j * L + x];
-          const float c = D[(size_t)(k - 1 - i) * L + i] + ws.cv[(size_t)j * L + x];
+          const uint32_t k = gck[(size_t)j * L + x];
+          const float c = D[(size_t)(k - 1 - i) * L + i] + gcv[(size_t)j * L + x];
           if (v < c) { v = c; t = k - i + 3; }
         }
         cur[i] = v;
@@ -206,24 +214,57 @@ __device__ float nuss_wg_span(uint32_t L, const float* __restrict__ S, const nus
   return buf[((L - 1) % 3) * Lr];
 }
 
-// nuss_traceback over the by-span codes of nuss_wg_span
-__device__ void nuss_traceback_span(uint32_t L, const uint32_t* __restrict__ T, uint32_t* ss, uint32_t* stack) {
+// The traceback over the by-span codes of nuss_wg_span, by one wavefront (cf. nuss_traceback_fast): the walk consists of
+// runs -- stretches of code 1 (i+1), of code 2 (j-1) and of stacked pairs (code 3) -- and the lanes read the next 64 cells
+// along the current direction at once; a ballot finds where the run ends and the lane that found it already holds the code
+// of the cell the walk lands on: one trip to the table per run instead of one per cell.  A bifurcation (code k - i + 3)
+// pairs (k, j), parks (i, k-1) on the stack (LDS, 16 + 16 bits) and goes on with (k+1, j-1).
+__device__ void nuss_traceback_span(uint32_t L, const uint32_t* __restrict__ T_, uint32_t* ss_, uint32_t* stack_, int lane) {
+  DD_GLB const uint32_t* T = (DD_GLB const uint32_t*)T_;
+  DD_LDS uint32_t* stack = (DD_LDS uint32_t*)stack_;
+  DD_GLB uint32_t* ss = (DD_GLB uint32_t*)ss_;
+  auto code = [&](int i, int j) -> uint32_t { return (i >= 0 && j > i && j < (int)L) ? T[(size_t)(j - i) * L + i] : 0u; };
   uint32_t sp = 0;
-  stack[0] = 0; stack[1] = L - 1; sp = 1;
+  int i = 0, j = (int)L - 1;
   uint32_t guard = 4 * L + 8;
-  while (sp && guard--) {
-    --sp;
-    const uint32_t i = stack[2 * sp], j = stack[2 * sp + 1];
-    const uint32_t t = T[(size_t)(j - i) * L + i];
-    if (t == 0) continue;
-    if (t == 1) { stack[2 * sp] = i + 1; stack[2 * sp + 1] = j; ++sp; }
-    else if (t == 2) { stack[2 * sp] = i; stack[2 * sp + 1] = j - 1; ++sp; }
-    else if (t == 3) { ss[i] = j; stack[2 * sp] = i + 1; stack[2 * sp + 1] = j - 1; ++sp; }
-    else {
-      const uint32_t k = i + t - 3;
-      stack[2 * sp] = i; stack[2 * sp + 1] = k - 1; ++sp;
-      ss[k] = j;
-      stack[2 * sp] = k + 1; stack[2 * sp + 1] = j - 1; ++sp;
+  uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)code(i, j));
+  while (guard--) {
+    if (t == 0) {
+      if (!sp) break;
+      --sp;
+      const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)stack[sp]);
+      i = (int)(e >> 16); j = (int)(e & 0xFFFFu);
+      t = (uint32_t)__builtin_amdgcn_readfirstlane((int)code(i, j));
+    } else if (t == 1) {
+      const uint32_t probe = code(i + 1 + lane, j);
+      const unsigned long long m = __ballot(probe != 1u);
+      const int r = m ? (int)__ffsll((long long)m) - 1 : 63;
+      i += 1 + r;
+      t = (uint32_t)__shfl((int)probe, r);
+    } else if (t == 2) {
+      const uint32_t probe = code(i, j - 1 - lane);
+      const unsigned long long m = __ballot(probe != 2u);
+      const int r = m ? (int)__ffsll((long long)m) - 1 : 63;
+      j -= 1 + r;
+      t = (uint32_t)__shfl((int)probe, r);
+    } else if (t == 3) {
+      const uint32_t probe = code(i + 1 + lane, j - 1 - lane);
+      const unsigned long long m = __ballot(probe != 3u);
+      const int r = m ? (int)__ffsll((long long)m) - 1 : 63;
+      if (lane == 0) ss[i] = (uint32_t)j;
+      if (lane < r) ss[i + 1 + lane] = (uint32_t)(j - 1 - lane);
+      i += 1 + r; j -= 1 + r;
+      t = (uint32_t)__shfl((int)probe, r);
+    } else {
+      const int k = i + (int)t - 3;
+      if (lane == 0) {
+        ss[k] = (uint32_t)j;
+        if (k - 1 > i) stack[sp] = ((uint32_t)i << 16) | (uint32_t)(k - 1);
+      }
+      if (k - 1 > i) ++sp;
+      wave_lds_fence();
+      i = k + 1; --j;
+      t = (uint32_t)__builtin_amdgcn_readfirstlane((int)code(i, j));
     }
   }
 }
@@ -342,10 +383,6 @@ __device__ bool nw_traceback(uint32_t L1, uint32_t L2, const uint8_t* tr, uint32
 // skewed by lane, the boundary column travels to the next lane by shuffle.  No barriers: the three
 // subproblems of an iteration run concurrently on three wavefronts of the workgroup.
 // ------------------------------------------------------------------------------------------
-// Address-space-qualified views: the wave DPs must compile to ds_* / global_* instructions, not flat_* ones (a flat
-// access counts on both wait counters, so an LDS operand would wait for every global store and load in flight)
-#define DD_LDS __attribute__((address_space(3)))
-#define DD_GLB __attribute__((address_space(1)))
 __device__ __forceinline__ float ld_l2(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_l2g(DD_GLB const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_l2g(DD_GLB float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1893,11 +1930,13 @@ __device__ __forceinline__ void dd_folder(const dd_node& nd, const dd_params& pr
         const float* Ss = isx ? nd.s_xs : nd.s_ys;
         const unsigned long long tf0 = prm.stamps ? wall_clock64() : 0ull;
         const float sc = K == 4 ? nuss_wg_span<4>(L, Ss, ws, lds) : K == 2 ? nuss_wg_span<2>(L, Ss, ws, lds) : nuss_wg_span<0>(L, Ss, ws, lds);
-        if (tid == 0) {
+        if (wave == 0) {
           const unsigned long long tf1 = prm.stamps ? wall_clock64() : 0ull;
-          nuss_traceback_span(L, ws.tr, ss, (uint32_t*)lds);  // the rolling rows are free again: 2(L+2) words of stack
-          s_fscore = sc;
-          if (prm.stamps) { nd.sync[isx ? 5 : 6] += (uint32_t)(tf1 - tf0); nd.sync[7] += (uint32_t)(wall_clock64() - tf1); }  // DP of x / y, tracebacks of both
+          nuss_traceback_span(L, ws.tr, ss, (uint32_t*)lds, lane);  // the rolling rows are free again: the stack
+          if (lane == 0) {
+            s_fscore = sc;
+            if (prm.stamps) { nd.sync[isx ? 5 : 6] += (uint32_t)(tf1 - tf0); nd.sync[7] += (uint32_t)(wall_clock64() - tf1); }  // DP of x / y, tracebacks of both
+          }
         }
       } else {
       nuss_pair_dp(L, isx ? nd.p_x : nd.p_y, isx ? nd.q_x : nd.q_y, wf, ws, 0, nullptr, nullptr, 0.0f, none, prm.th_s);
