@@ -129,8 +129,11 @@ __device__ void nuss_pair_dp(uint32_t LA, const float* pA, const float* qA, floa
 //   * dp and the traceback codes are written by span, D[(j-i)*L + i] (the arrays of nuss_ws, re-indexed): coalesced stores that
 //     nobody waits for -- a bifurcation reads dp[i][k-1] with k <= j-3, a cell written at least four barriers earlier.
 // Same cells, same comparisons in the same order as nuss_cell, so the same table, codes and structure.
-template <int K>
-__device__ float nuss_wg_span(uint32_t L, const float* __restrict__ S_, const nuss_ws& ws, float* lds) {
+// DIRECT (the standalone decoder, which has no by-span copy): the score comes from p (and q) as nuss_cell computes it, a
+// strided read per cell, still a span ahead.
+template <int K, bool DIRECT = false>
+__device__ float nuss_wg_span(uint32_t L, const float* __restrict__ S_, const nuss_ws& ws, float* lds, const float* __restrict__ q_ = nullptr,
+                              float w = 0.0f, float th = 0.0f) {
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const uint32_t Lr = (L + 3) & ~3u, Lp = (L + 63) & ~63u;
   // address-space-qualified views (see DD_LDS): a flat access to LDS would wait for every global store in flight
@@ -139,6 +142,14 @@ __device__ float nuss_wg_span(uint32_t L, const float* __restrict__ S_, const nu
   DD_LDS uint32_t* hk = cc + Lr;
   DD_LDS float* hv = (DD_LDS float*)(hk + (K ? K : 1) * Lr);
   DD_GLB const float* S = (DD_GLB const float*)S_;
+  DD_GLB const float* Q = (DD_GLB const float*)q_;
+  auto score = [&](uint32_t l, uint32_t i) -> float {  // s of cell (i, i + l); 0 where the reference's span test fails
+    if constexpr (DIRECT) {
+      if (l < 3) return 0.0f;
+      const size_t o = (size_t)i * L + i + l;
+      return Q ? w * (S[o] - th) - Q[o] : S[o] - th;  // nussinov.cpp:236 / :329
+    } else return S[(size_t)l * Lp + i];
+  };
   DD_GLB float* D = (DD_GLB float*)ws.dp;
   DD_GLB uint32_t* T = (DD_GLB uint32_t*)ws.tr;
   DD_GLB uint32_t* gck = (DD_GLB uint32_t*)ws.ck;
@@ -151,7 +162,7 @@ __device__ float nuss_wg_span(uint32_t L, const float* __restrict__ S_, const nu
   constexpr int U = 4;  // cells of a thread whose loads are in flight together
   float s_ahead[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) { const uint32_t i = tid + u * nt; s_ahead[u] = (2 < L && i < L - 2) ? S[(size_t)2 * Lp + i] : 0.0f; }
+  for (int u = 0; u < U; ++u) { const uint32_t i = tid + u * nt; s_ahead[u] = (2 < L && i < L - 2) ? score(2, i) : 0.0f; }
   __syncthreads();
   for (uint32_t l = 2; l < L; ++l) {
     DD_LDS const float* p1 = buf + ((l - 1) % 3) * Lr;
@@ -167,7 +178,7 @@ __device__ float nuss_wg_span(uint32_t L, const float* __restrict__ S_, const nu
         n[u] = 0;
         sc[u] = 0.0f;
         if (i < ncell) {
-          sc[u] = base == 0 ? s_ahead[u] : S[(size_t)l * Lp + i];
+          sc[u] = base == 0 ? s_ahead[u] : score(l, i);
           n[u] = cc[j];
 #pragma unroll
           for (int x = 0; x < K; ++x)
@@ -180,7 +191,7 @@ __device__ float nuss_wg_span(uint32_t L, const float* __restrict__ S_, const nu
       }
       if (base == 0 && l + 1 < L) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const uint32_t i = tid + u * nt; s_ahead[u] = i < ncell - 1 ? S[(size_t)(l + 1) * Lp + i] : 0.0f; }
+        for (int u = 0; u < U; ++u) { const uint32_t i = tid + u * nt; s_ahead[u] = i < ncell - 1 ? score(l + 1, i) : 0.0f; }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1158,9 +1169,20 @@ __device__ void dd_fill_nw(uint32_t L1, uint32_t L2, uint32_t W, const float* __
 // ------------------------------------------------------------------------------------------
 // standalone decoders (Fold::Decoder / Align::Decoder plugin calls)
 // ------------------------------------------------------------------------------------------
+// heads: candidates per column the workgroup form keeps in LDS (4 / 2 / 0), or DD_NONE when not even its rolling rows fit
+// (beyond ~9 900 columns): the span-ordered form on global tables then
 __global__ __launch_bounds__(DD_THREADS) void k_nussinov_single(uint32_t L, const float* p, const float* q, float w, float th,
-                                                                nuss_ws ws, uint32_t* ss, float* score) {
+                                                                nuss_ws ws, uint32_t* ss, float* score, uint32_t heads) {
+  extern __shared__ unsigned char s_dd[];
   for (uint32_t i = threadIdx.x; i < L; i += blockDim.x) ss[i] = DD_NONE;
+  if (heads != DD_NONE && L >= 3) {
+    float* lds = (float*)(((uintptr_t)s_dd + 15) & ~(uintptr_t)15);
+    const float sc = heads == 4 ? nuss_wg_span<4, true>(L, p, ws, lds, q, w, th) : heads == 2 ? nuss_wg_span<2, true>(L, p, ws, lds, q, w, th)
+                                                                                              : nuss_wg_span<0, true>(L, p, ws, lds, q, w, th);
+    if (threadIdx.x < 64) nuss_traceback_span(L, ws.tr, ss, (uint32_t*)lds, (int)threadIdx.x);
+    if (threadIdx.x == 0) *score = sc;
+    return;
+  }
   nuss_ws none = {nullptr, nullptr, nullptr, nullptr, nullptr};
   nuss_pair_dp(L, p, q, w, ws, 0, nullptr, nullptr, 0.0f, none, th);
   if (threadIdx.x == 0) {
@@ -2397,7 +2419,7 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
 // ------------------------------------------------------------------------------------------
 // dynamic-LDS opt-in above 64 KB, once per device and kernel
 static int lds_optin(const void* fn, int slot, size_t bytes, size_t budget = kDdLdsBudget) {
-  static bool done[4][16] = {{false}};
+  static bool done[5][16] = {{false}};
   int dev = 0;
   if (hip_check(hipGetDevice(&dev))) return DAFS_HIP_ENODEV;
   if (bytes <= 64 * 1024) return DAFS_HIP_OK;
@@ -2491,7 +2513,16 @@ int dd_solve_launch(const dd_node* d_nodes, uint32_t nnodes, dd_params prm, size
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 int nussinov_launch(uint32_t L, const float* p, const float* q, float w, float th, nuss_ws ws, uint32_t* ss, float* score, hipStream_t st) {
-  STAGE_LAUNCH(ST_NUSSINOV_SINGLE, st) hipLaunchKernelGGL(k_nussinov_single, dim3(1), dim3(DD_THREADS), 0, st, L, p, q, w, th, ws, ss, score);
+  uint32_t heads = DD_NONE;
+  size_t lds = 0;
+  if (!getenv("DAFS_HIP_NUSS_GLOBAL"))  // tests: keep the span-ordered form on global tables
+    for (uint32_t K : {4u, 2u, 0u})
+      if ((size_t)dd_wg_words(L, K) * 4 + 16 <= kDdLdsBudget) { heads = K; lds = (size_t)dd_wg_words(L, K) * 4 + 16; break; }
+  if (lds > 64 * 1024) {
+    const int rc = lds_optin((const void*)k_nussinov_single, 4, lds);
+    if (rc) return rc;
+  }
+  STAGE_LAUNCH(ST_NUSSINOV_SINGLE, st) hipLaunchKernelGGL(k_nussinov_single, dim3(1), dim3(DD_THREADS), lds, st, L, p, q, w, th, ws, ss, score, heads);
   return hip_check(hipGetLastError()) ? DAFS_HIP_ELAUNCH : DAFS_HIP_OK;
 }
 int nussinov_dense_launch(uint32_t L, const float* p, const float* q, float w, float th, float* dp, uint32_t* tr, uint32_t* stack, uint32_t* ss,

@@ -58,6 +58,29 @@ def test_decoders_fuzz_vs_oracle(ctx, oracle):
         assert np.float32(a[0]).tobytes() == np.float32(b[0]).tobytes() and np.array_equal(a[1], b[1]), (t, L, L2)
 
 
+def test_nussinov_decoder_forms_vs_oracle(ctx, oracle, monkeypatch):
+    """The standalone folding decoder takes the workgroup form (rolling rows + candidate heads in LDS) up to ~9 900 columns and
+    the span-ordered form on global tables beyond; DAFS_HIP_NUSS_GLOBAL=1 keeps the latter at any width.  Both against the
+    oracle, with quantised inputs (ties) and dense ones (more candidates per column than the on-chip heads)."""
+    rng = np.random.default_rng(78)
+    cases = []
+    for t in range(12):
+        L = int(rng.choice([3, 5, 64, 65, 130, 257, 600]))
+        dens = float(rng.choice([0.02, 0.2, 0.6]))
+        p = (rng.random((L, L)) * (rng.random((L, L)) < dens)).astype(np.float32)
+        if t % 2:
+            p = (np.round(p * 4) / 4).astype(np.float32)
+        q = ((rng.random((L, L)) - 0.4) * (rng.random((L, L)) < 0.3)).astype(np.float32) if t % 3 else None
+        w, th = float(rng.choice([4.0, 1.3333334])), float(rng.choice([0.2, 0.05]))
+        cases.append((p, q, th, w, oracle.nussinov(p, q, th, w)))
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("DAFS_HIP_NUSS_GLOBAL", env)
+        for k, (p, q, th, w, b) in enumerate(cases):
+            a = ctx.nussinov(p, q, th, w)
+            assert np.float32(a[0]).tobytes() == np.float32(b[0]).tobytes() and np.array_equal(a[1], b[1]), (env, k, p.shape[0])
+
+
 def _run_both(oracle, names, seqs, bp, **kw):
     from dafs_amd import pipeline
     okw = dict(fold_model=1)

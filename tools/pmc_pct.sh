@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over the consistency stage of the headline set (tools/scratch/pct_time.py): instruction mix, waits, LDS conflicts and
+# PMC passes over the consistency stage of the headline set (tools/time_pct.py): instruction mix, waits, LDS conflicts and
 # the L1 / L2 request counters of k_pct_rows (--kernel-trace only, one pass per counter group).  Usage: bash tools/pmc_pct.sh <outdir> [N L]
 out=${1:-gpurun_out/pmc_pct}
 n=${2:-128}; l=${3:-150}
@@ -15,7 +15,7 @@ for grp in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_W
            "TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum TA_BUSY_avr TA_TA_BUSY_sum" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$root/$out/p$i" -o p -- python3 "$root/tools/scratch/pct_time.py" $n $l > "$root/$out/p$i.log" 2>&1 || echo "group $i failed: $grp"
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$root/$out/p$i" -o p -- python3 "$root/tools/time_pct.py" $n $l > "$root/$out/p$i.log" 2>&1 || echo "group $i failed: $grp"
 done
 cd "$root"
 python3 - "$out" <<'PY'
