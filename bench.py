@@ -555,8 +555,31 @@ def main():
             iso = (ctx.stage_report(), (int(o["iterations"]), int(lens[0]), int(lens[1]), int(o["ncbp"])))
         except capi.DafsHipError:
             iso = None
+        # the phase-1 kernels once more, each alone on the device (inside a whole run the folding kernel runs beside the pair
+        # and consistency kernels and shares the CUs with them): the numbers a per-kernel roofline should be read from
+        alone = {}
+        try:
+            ctx.set_sequences(seqs)
+            ctx.stage_report()
+            ctx.fold_posteriors(0.01)
+            alone.update(ctx.stage_report())
+            ctx.align_posteriors(capi.ALIGN_CONTRALIGN, args.th, fetch=False)
+            alone.update(ctx.stage_report())
+            ctx.align_posteriors(capi.ALIGN_PROBCONS, args.th, fetch=False)
+            alone.update(ctx.stage_report())
+            ctx.consistency_match(0.25)
+            alone.update(ctx.stage_report())
+            ctx.consistency_bp(0.25)
+            alone.update(ctx.stage_report())
+        except capi.DafsHipError:
+            alone = {}
         ctx.stage_timing(False)
         stages = stage_objects(ctx, seqs, lens, contra, rep, iso)
+        if alone:
+            solo = stage_objects(ctx, seqs, lens, contra, alone, None)
+            stages["alone"] = {k.replace(" (inside the whole run)", ""): {a: b for a, b in v.items() if a in ("ms", "launches", "algorithmic_bytes", "achieved_GBps", "frac", "frac_of_valu_peak")}
+                               for k, v in solo.items()}
+            stages["alone"]["note"] = "each kernel by itself on the same set (ProbCons store for the transforms); k_pairhmm5 = the CONTRAlign pair kernel, 44*(L1+1)(L2+1) B per pair"
         ctx.close()
 
     if rank == 0:

@@ -1,5 +1,5 @@
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from dafs_amd import capi, synth, pipeline
 fam = len(sys.argv) > 1 and sys.argv[1] == "family"
 recs = synth.family_set(512, 400, seed=12346) if fam else synth.random_set(512, 400, seed=12345)

@@ -1,6 +1,6 @@
 """per-kernel device times of one c5 run (dafs_hip_stage_timing); usage: c5_stages.py [family|random] [N L]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from dafs_amd import capi, synth, pipeline
 fam = len(sys.argv) > 1 and sys.argv[1] == "family"
 n, L = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (512, 400)

@@ -1,5 +1,5 @@
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from dafs_amd import capi, synth
 n, L = int(sys.argv[1]), int(sys.argv[2])
 recs = synth.random_set(n, L, seed=12345)
