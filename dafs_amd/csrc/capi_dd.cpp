@@ -32,6 +32,27 @@ struct carver {
 
 struct region { size_t off, bytes; int value; };
 
+void carve_nuss(carver& cv, uint32_t L, nuss_ws& w);
+// What only the folding DPs touch -- their work arrays (16 L^2 bytes each), the HBM copies of the traceback codes and the
+// pair scores in the order the DPs read them (sweep order for the column-owning forms unless no launch uses them, by span
+// for the span and workgroup forms; nd.lds_flags / nd.fold_fast say which) -- goes into the node's SECOND block, which is
+// carved when the consensus-pair count is known: a node that leaves its foldings out (dafs_dd_params::skip_uncoupled_folds and
+// no consensus pair) gets none of it, a third of its memory instead of all (27 GB -> 9 GB at the 27 000-column root of c5-random).
+void carve_folding(carver& cv, dd_node& nd, bool force_wide) {
+  const uint32_t L1 = nd.L1, L2 = nd.L2;
+  const size_t XX = (size_t)L1 * L1, YY = (size_t)L2 * L2;
+  carve_nuss(cv, L1, nd.wx);
+  carve_nuss(cv, L2, nd.wy);
+  nd.trk_x = nd.wx.tr; nd.trk_y = nd.wy.tr;  // the L*L uint32 tables double as bifurcation codes
+  nd.trb_x = cv.take<uint8_t>(XX / 2 + L1 + 16); nd.trb_y = cv.take<uint8_t>(YY / 2 + L2 + 16);
+  const bool span_only = (nd.lds_flags & 64u) != 0;
+  const bool span_any = span_only || (nd.fold_fast & (16u | 32u)) != 0;
+  nd.s_x = (dd_fold_cols(L1) <= DD_WFOLD && !force_wide && !span_only) ? cv.take<float>(((size_t)L1 + 63) * dd_fold_cols(L1) * 64) : nullptr;
+  nd.s_y = (dd_fold_cols(L2) <= DD_WFOLD && !force_wide && !span_only) ? cv.take<float>(((size_t)L2 + 63) * dd_fold_cols(L2) * 64) : nullptr;
+  nd.s_xs = (span_any || (nd.fold_fast & 64u)) ? cv.take<float>((size_t)L1 * ((L1 + 63) & ~63u) + 64) : nullptr;
+  nd.s_ys = (span_any || (nd.fold_fast & 128u)) ? cv.take<float>((size_t)L2 * ((L2 + 63) & ~63u) + 64) : nullptr;
+}
+
 void carve_nuss(carver& cv, uint32_t L, nuss_ws& w) {
   const size_t LL = (size_t)L * L;
   w.dp = cv.take<float>(LL + 1);
@@ -231,19 +252,23 @@ dd_lane lane_of(dafs_hip_ctx* c, int k) { return k == 0 ? dd_lane{c->stream, &c-
 // fault of round 2 ("the fault at 16 x ~1100 columns": the multiplier updates wrote s_x[skew(i, j)] of
 // nodes beyond 1024 columns, whose s_x had just become optional).  The kernel's writes are guarded now; this check
 // turns any future mismatch between the carving and the form selection into DAFS_HIP_ELAUNCH instead of a fault.
-int plan_check(const dd_node& nd, bool split) {
+// folds: this launch runs the node's folding DPs (the kernel's fold_on: not (skip_uncoupled_folds and no consensus pair))
+int plan_check(const dd_node& nd, bool split, bool folds) {
   auto bad = [](const char* what) {
     fprintf(stderr, "dafs_hip: node plan refused: %s\n", what);
     return DAFS_HIP_ELAUNCH;
   };
   const void* always[] = {nd.seq1, nd.seq2, nd.rank1, nd.rank2, nd.idx1, nd.idx2, nd.idxoff1, nd.idxoff2, nd.p_x, nd.p_y, nd.p_z, nd.q_x, nd.q_y, nd.q_z,
-                          nd.wx.dp, nd.wx.tr, nd.wx.ck, nd.wx.cv, nd.wx.cc, nd.wy.dp, nd.wy.tr, nd.wy.ck, nd.wy.cv, nd.wy.cc, nd.nw_edge, nd.tr_z,
-                          nd.trb_x, nd.trb_y, nd.trk_x, nd.trk_y, nd.pz_s, nd.qz_s, nd.env, nd.env4, nd.xmap, nd.ymap, nd.zmap, nd.px_ptr, nd.px_j,
+                          nd.nw_edge, nd.tr_z, nd.pz_s, nd.qz_s, nd.env, nd.env4, nd.xmap, nd.ymap, nd.zmap, nd.px_ptr, nd.px_j,
                           nd.py_ptr, nd.py_l, nd.pz_ptr, nd.pz_k, nd.cz_ptr, nd.cz_k, nd.cx_flag, nd.cy_flag, nd.cz_flag, nd.cbp_cnt, nd.cbp, nd.sw,
                           nd.tx, nd.ty, nd.tz, nd.x, nd.y, nd.z, nd.score, nd.info, nd.fstate, nd.sync};
   for (const void* q : always)
     if (!q) return bad("a null array in the node descriptor");
   if (!nd.L1 || !nd.L2 || !nd.n1 || !nd.n2) return bad("empty child alignment");
+  if (!folds) return DAFS_HIP_OK;  // nothing below is touched
+  const void* folding[] = {nd.wx.dp, nd.wx.tr, nd.wx.ck, nd.wx.cv, nd.wx.cc, nd.wy.dp, nd.wy.tr, nd.wy.ck, nd.wy.cv, nd.wy.cc, nd.trb_x, nd.trb_y, nd.trk_x, nd.trk_y};
+  for (const void* q : folding)
+    if (!q) return bad("a node that folds without its folding arrays (opened with skip_uncoupled_folds, advanced without?)");
   const bool regx = dd_fold_cols(nd.L1) <= DD_WFOLD, regy = dd_fold_cols(nd.L2) <= DD_WFOLD;
   if (!split) {
     const uint32_t f = nd.lds_flags;
@@ -339,17 +364,15 @@ int nodes_open_impl(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const d
       const size_t m0 = (cv.used + 255) & ~(size_t)255;
       nd.xmap = cv.take<int32_t>(XX); nd.ymap = cv.take<int32_t>(YY); nd.zmap = cv.take<int32_t>(ZZ);
       fills.push_back({m0, cv.used - m0, 0xFF});
-      carve_nuss(cv, L1, nd.wx);
-      carve_nuss(cv, L2, nd.wy);
+      // (the folding DPs' work arrays, codes and score copies are carved into the node's second block, once the
+      // consensus-pair count says whether this node folds at all: carve_folding below)
       // the alignment DP: columns per lane, and with them the panels of second alignments beyond 64 nw_w - 1 columns
       nd.nw_w = force_wide ? 1u : dd_nw_cols(L2);
       const size_t nw_panels = dd_nw_panels(L2, nd.nw_w);
       nd.nw_edge = cv.take<float>(2 * ((size_t)L1 + 2));
       nd.tr_z = cv.take<uint8_t>(nw_panels * (L1 + 1) * 512);  // a 64-bit slot per (panel, row, lane)
-      nd.trb_x = cv.take<uint8_t>(XX / 2 + L1 + 16); nd.trb_y = cv.take<uint8_t>(YY / 2 + L2 + 16);
-      // steps x columns per lane x 64 lanes; only for foldings that have a register form
+      // sweep-order inputs of the alignment DP: steps x columns per lane x 64 lanes, panel by panel
       nd.pz_s = cv.take<float>(nw_panels * ((size_t)L1 + 63) * nd.nw_w * 64); nd.qz_s = cv.take<float>(nw_panels * ((size_t)L1 + 63) * nd.nw_w * 64);
-      nd.trk_x = nd.wx.tr; nd.trk_y = nd.wy.tr;  // the L*L uint32 tables double as bifurcation codes
       {  // LDS plan (mirrors the carving at the top of k_dd_solve / dd_folder)
         auto nib = [](uint32_t L) { return ((size_t)L * (L + 1) / 2 + 7) / 8; };           // packed traceback codes, words
         // a fast folding DP: codes, the rows in flight (one per active lane), DD_CAP split rows per column
@@ -419,16 +442,6 @@ int nodes_open_impl(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const d
           if (nd.fold_fast || !wide_ok(L1, DD_WFOLD) || !wide_ok(L2, DD_WFOLD)) split_lds[b] = std::max(worst, used);
         }
       }
-      // pair scores in the order the folding DPs read them: sweep order (steps x columns per lane x 64 lanes) for the
-      // column-owning forms unless no launch uses them, by span for the span form
-      {
-        const bool span_only = (nd.lds_flags & 64u) != 0;
-        const bool span_any = span_only || (nd.fold_fast & (16u | 32u)) != 0;
-        nd.s_x = (dd_fold_cols(L1) <= DD_WFOLD && !force_wide && !span_only) ? cv.take<float>(((size_t)L1 + 63) * dd_fold_cols(L1) * 64) : nullptr;
-        nd.s_y = (dd_fold_cols(L2) <= DD_WFOLD && !force_wide && !span_only) ? cv.take<float>(((size_t)L2 + 63) * dd_fold_cols(L2) * 64) : nullptr;
-        nd.s_xs = (span_any || (nd.fold_fast & 64u)) ? cv.take<float>((size_t)L1 * ((L1 + 63) & ~63u) + 64) : nullptr;
-        nd.s_ys = (span_any || (nd.fold_fast & 128u)) ? cv.take<float>((size_t)L2 * ((L2 + 63) & ~63u) + 64) : nullptr;
-      }
       nd.env = cv.take<uint32_t>(2 * ((size_t)L1 + 1));
       nd.env4 = cv.take<uint32_t>(2 * ((size_t)L1 + 130));
       nd.px_ptr = cv.take<uint32_t>((size_t)L1 + 2); nd.px_j = cv.take<uint32_t>(XX / 2 + 2);
@@ -494,6 +507,7 @@ int nodes_open_impl(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const d
       nodes[b].ncbp_cap = ncbp;
       nodes[b].cbp = cb.take<uint32_t>((size_t)8 * ncbp + 8);
       nodes[b].sw = cb.take<float>((size_t)ncbp + 1);
+      if (!(dp.skip_xy && ncbp == 0)) carve_folding(cb, nodes[b], force_wide);  // the kernel's fold_on
       if (pass == 0) {
         cb.base = c->dd_alloc(cb.used + 256);
         if (!cb.base) return DAFS_HIP_ENOMEM;
@@ -503,7 +517,7 @@ int nodes_open_impl(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const d
   }
   if (fail_injected(3)) return DAFS_HIP_ELAUNCH;
   for (uint32_t b = 0; b < nnodes; ++b)  // both placements a launch may choose for this node, before anything runs on it
-    if ((rc = plan_check(nodes[b], false))) return rc;
+    if ((rc = plan_check(nodes[b], false, !(dp.skip_xy && counts[b] == 0)))) return rc;
   if ((rc = ln.d_nodes->upload(nodes.data(), nnodes, ln.st))) return rc;
   if ((rc = dd_cbp_fill_launch(ln.d_nodes->ptr, nnodes, force_wide ? 0 : max_len, dp, ln.st))) return rc;
   if (fail_injected(4)) return DAFS_HIP_ELAUNCH;
@@ -585,7 +599,7 @@ int advance_launch(dafs_hip_ctx* c, const dd_lane& ln, uint32_t n, const uint32_
   dp.slice = max_iterations;
   int rc;
   for (size_t b = 0; b < nodes.size(); ++b)  // the form each node takes in THIS launch against what its block holds
-    if ((rc = plan_check(nodes[b], nodes[b].split != 0))) return rc;
+    if ((rc = plan_check(nodes[b], nodes[b].split != 0, !(dp.skip_xy && nodes[b].ncbp_cap == 0)))) return rc;
   if ((rc = ln.d_nodes->upload(nodes.data(), nodes.size(), ln.st))) return rc;
   if ((rc = ln.d_paused->reserve(nodes.size()))) return rc;
   for (size_t b = 0; b < nodes.size(); ++b) c->dd_open[handles[who[b]]].in_flight = true;

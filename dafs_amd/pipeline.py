@@ -226,6 +226,7 @@ def _phase2(ctx, own, names, seqs, n, sim, score, left, right, t, w, eta0, t_max
             res.levels += 1
         res.dd_memory = ctx.nodes_memory()  # (reserved, in use, peak) bytes of the resident nodes
         res.dd_demotions = ctx.nodes_demotions()  # split nodes that lost their folders (0 on an undisturbed device)
+        res.skip_uncoupled_folds = bool(skip_uncoupled_folds)  # nodes without consensus pairs then carry no folding arrays
         ctx.nodes_close()
     root = 2 * n - 2
     sidx, mask = aln[root]

@@ -187,11 +187,15 @@ def test_c5_whole_run_properties(which):
     assert time.time() - t0 < 300
 
 
-def _node_bytes_bound(l1, l2):
-    """upper bound of a resident node's device memory from its dimensions (capi_dd.cpp nodes_open: per cell of the L x L
-    folding tables p, q 8 + flags 0.5 + id map 4 + Nussinov work arrays 16 + byte codes 0.5 + lists and counters 6 +
-    up to two score copies 8 = 43 bytes; per cell of the L1 x L2 alignment tables 38 bytes; row arrays and padding)"""
-    return 43 * (l1 * l1 + l2 * l2) + 38 * (l1 + 1) * (l2 + 1) + 4096 * (l1 + l2) + (1 << 16)
+def _node_bytes_bound(l1, l2, folds=True):
+    """upper bound of a resident node's device memory from its dimensions (capi_dd.cpp nodes_open).  First block: per cell
+    of the L x L matrices p, q 8 + flags 0.5 + id map 4 + lists and counters 6 = 18.5 bytes, per cell of the L1 x L2
+    alignment tables 26 bytes (p, q, flags, map, lists) + its two sweep-order input copies (8 bytes per padded cell) + 512 bytes
+    of traceback slots per row and panel, row arrays and padding.  Second block, only when the node folds (it has consensus pairs, or skip_uncoupled_folds is off): per cell of
+    L x L the Nussinov work arrays 16 + byte codes 0.5 + up to two score copies 8 = 24.5 bytes."""
+    first = (19 * (l1 * l1 + l2 * l2) + 26 * (l1 + 1) * (l2 + 1) + 8 * (l1 + 63) * (l2 + 64) + 512 * (l1 + 1) * ((l2 + 2048) // 2048)
+             + 128 * (l1 + l2) + (1 << 14))
+    return first + (25 * (l1 * l1 + l2 * l2) if folds else 0)
 
 
 def _check_arena(res):
@@ -201,7 +205,8 @@ def _check_arena(res):
     reserved, in_use, peak = res.dd_memory
     assert in_use == 0
     cbp = {i: v[2] for i, v in res.dd_log.items()}
-    expected = max(sum(_node_bytes_bound(l1, l2) + 36 * cbp[i] + 1024 for i, l1, l2 in nodes) for _, nodes in res.rounds)
+    folds = lambda i: cbp[i] > 0 or not res.skip_uncoupled_folds
+    expected = max(sum(_node_bytes_bound(l1, l2, folds(i)) + 36 * cbp[i] + 1024 for i, l1, l2 in nodes) for _, nodes in res.rounds)
     assert peak <= expected, (peak, expected)
     assert peak >= expected / 3, (peak, expected)   # and the bound is not vacuous
 
@@ -330,6 +335,13 @@ def test_node_arena_returns_memory():
     _check_arena(res)
     everything = sum(_node_bytes_bound(l1, l2) for l1, l2 in res.dd_dims.values())
     assert res.dd_memory[2] < everything / 2           # far below what the whole tree would take
+    # nodes without consensus pairs leave their foldings out and then carry no folding arrays (the second block is carved
+    # after the count): with the reference's behaviour (every node folds) the same run needs more, and says the same
+    full = pipeline.run(names, seqs, skip_uncoupled_folds=False)
+    _check_arena(full)
+    assert full.output == res.output
+    if any(v[2] == 0 for v in res.dd_log.values()):
+        assert res.dd_memory[2] < full.dd_memory[2]
 
 
 def test_wide_contralign_nodes_at_the_round2_fault_shape(oracle):
