@@ -172,21 +172,31 @@ __device__ float nuss_wg_span(uint32_t L, const float* __restrict__ S_, const nu
     for (uint32_t base = 0; base < ncell; base += U * nt) {
       float sc[U], g[U][K ? K : 1], hvx[U][K ? K : 1];
       uint32_t kk[U][K ? K : 1], n[U];
+      // Everything a cell reads from memory, in three batches without a branch between them (as separate conditional blocks
+      // every candidate cost the cell a dependent LDS round trip of its own): the counters, then all K heads of all U cells
+      // whether they are filled or not, then the gathers with the unfilled ones pointed at dp[i][i] -- one LDS trip, one
+      // more, one trip to the table per span.
+      uint32_t ci[U];  // the cell's row, clamped into the span for the lanes beyond it (they read, and discard)
 #pragma unroll
-      for (int u = 0; u < U; ++u) {  // everything a cell reads from memory
-        const uint32_t i = base + u * nt + tid, j = i + l;
-        n[u] = 0;
-        sc[u] = 0.0f;
-        if (i < ncell) {
-          sc[u] = base == 0 ? s_ahead[u] : score(l, i);
-          n[u] = cc[j];
+      for (int u = 0; u < U; ++u) {
+        const uint32_t i = base + u * nt + tid;
+        ci[u] = i < ncell ? i : ncell - 1;
+        n[u] = cc[ci[u] + l];
+      }
 #pragma unroll
-          for (int x = 0; x < K; ++x)
-            if ((uint32_t)x < n[u]) {
-              kk[u][x] = hk[x * Lr + j];
-              hvx[u][x] = hv[x * Lr + j];
-              g[u][x] = D[(size_t)(kk[u][x] - 1 - i) * L + i];
-            }
+      for (int u = 0; u < U; ++u) {
+        const uint32_t i = base + u * nt + tid;
+        sc[u] = i < ncell ? (base == 0 ? s_ahead[u] : score(l, i)) : 0.0f;
+#pragma unroll
+        for (int x = 0; x < K; ++x) { kk[u][x] = hk[x * Lr + ci[u] + l]; hvx[u][x] = hv[x * Lr + ci[u] + l]; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (base + u * nt + tid >= ncell) n[u] = 0;
+#pragma unroll
+        for (int x = 0; x < K; ++x) {
+          const uint32_t d = (uint32_t)x < n[u] ? kk[u][x] - 1 - ci[u] : 0u;  // span of dp[i][k-1]; an unfilled head reads dp[i][i]
+          g[u][x] = D[(size_t)(d < l ? d : 0u) * L + ci[u]];
         }
       }
       if (base == 0 && l + 1 < L) {
