@@ -30,6 +30,23 @@ def test_strerror_and_codes():
     assert b"unknown" in capi._strerror(-99)
 
 
+def test_pair_ranges_of_the_sharded_phase_agree_with_the_python_driver():
+    """dafs_hip_pair_range (what dafs --devices shards by) = dist.pair_ranges (what the torch driver shards by): contiguous,
+    covering, in rank order -- so the ranks' shards concatenated in rank order are the whole in pair order"""
+    from dafs_amd import capi, dist
+    assert capi._strerror(-7).startswith(b"dafs_hip: the collective")
+    f = capi.lib.dafs_hip_pair_range
+    f.restype = None
+    f.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    for npairs in (0, 1, 3, 8128, 130816, 10 ** 12 + 7):
+        for world in (1, 2, 3, 8, 64):
+            want = dist.pair_ranges(npairs, world)
+            for r in range(world):
+                b, e = C.c_uint64(), C.c_uint64()
+                f(npairs, world, r, C.byref(b), C.byref(e))
+                assert (b.value, e.value) == (want[r], want[r + 1]), (npairs, world, r)
+
+
 def test_residue_codes():
     from dafs_amd import capi
     assert list(capi.encode("ACGUTNacgutn")) == [0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5]
