@@ -324,8 +324,8 @@ int nodes_open_impl(dafs_hip_ctx* c, const dd_lane& ln, uint32_t nnodes, const d
   }
 
   // DAFS_HIP_DD_WIDE=1 (tests): every node takes the forms of alignments too wide for the on-chip placements -- foldings
-  // span-ordered on HBM tables without sweep-order copies, the alignment wave DP without input row buffers, row
-  // pointers searched in HBM, one averaging row per workgroup
+  // span-ordered on HBM tables without sweep-order copies, the alignment DP in panels of 64 columns with its codes in
+  // HBM slots, row pointers searched in HBM, one averaging row per workgroup
   const char* wide_env = getenv("DAFS_HIP_DD_WIDE");
   const bool force_wide = wide_env && atoi(wide_env) != 0;
   // ---- carve each node's block (two passes: size, then pointers) ----

@@ -17,13 +17,14 @@
 // candidate split points and traceback codes in LDS (the codes in HBM from ~415 columns on; 48 lanes of up
 // to 16 columns from 513 to 768), followed by their tracebacks (the folding one by the whole wavefront, run
 // by run); the multiplier update is parallel over the sparse consensus structure.
-// A folding DP that has no register form (beyond 768 columns) or whose register form overflows its candidate
-// slots falls back to the span-ordered form of the standalone decoder on all threads of its workgroup
-// (nuss_pair_dp); an alignment DP that does not fit falls back to the wave form over HBM/L2 tables (nw_wave).  Float sums
-// that the reference forms sequentially (the dual value s, which steers the step size) are formed in the
+// A folding DP that has no register form (beyond 1024 columns) runs span-ordered on all threads of its folder's
+// workgroup with its rows in flight in LDS (nuss_wg_span); one whose register form overflows its candidate slots falls
+// back to the span-ordered form on global tables (nuss_pair_dp).  The alignment DP stays in registers at any width: beyond
+// 16 columns per lane its traceback codes go to HBM slots, beyond 2047 columns it runs in column panels (nw_wave_reg).
+// Float sums that the reference forms sequentially (the dual value s, which steers the step size) are formed in the
 // same order: positive terms are compacted in consensus-pair order and added by one lane.
-// The standalone decoders (k_nussinov_single, k_nw_single: the plugin entry points and the final consensus
-// structure) use the older barrier-per-diagonal forms below.
+// The standalone decoders (the plugin entry points and the final consensus structure): k_nussinov_single takes the
+// workgroup form up to ~9 900 columns, k_nw_single the barrier-per-diagonal form below.
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <stdint.h>
@@ -410,8 +411,6 @@ __device__ __forceinline__ void st_l2g(DD_GLB float* p, float v) { __hip_atomic_
 __device__ __forceinline__ void st_l2(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ size_t tri_index(uint32_t L, uint32_t i, uint32_t j) { return (size_t)i * L - (size_t)i * (i - 1) / 2 + (j - i); }  // j >= i
 
-#define DD_WMAX 16  // columns per lane whose next-step inputs are prefetched through registers by nw_wave; wider lanes (alignments
-                   // beyond 1024 columns, up to DD_LMAX) fetch the rest at the end of the step
 
 // Register-resident forms (W columns per lane, a template constant: up to DD_WNW for the alignment DP, DD_WREG for
 // the folding DP with its codes in LDS, up to DD_WFOLD for the folding DP with its codes in HBM): the previous
@@ -2031,8 +2030,8 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     if (resume) { c = nd.fstate[0]; eta = nd.fstate[1]; s_prev = nd.fstate[2]; }
     s_eta = eta; s_bad = 0; s_lost = 0;
   }
-  // dynamic LDS: previous-row buffers and candidate counters of the three wave DPs, then whichever
-  // traceback tables fit (nd.lds_flags, decided by the host): bit 0 alignment, bit 1 x, bit 2 y
+  // dynamic LDS: whichever traceback tables and in-flight rows fit (nd.lds_flags, decided by the host): bit 0 alignment,
+  // bit 1 x, bit 2 y
   extern __shared__ unsigned char s_dd[];
   const uint32_t Wx = dd_fold_cols(L1), Wy = dd_fold_cols(L2), Wz = nd.nw_w;
   // previous-row buffers and candidate counters of the HBM-table folding forms: room of their own only when the
