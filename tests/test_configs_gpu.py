@@ -279,6 +279,57 @@ def test_alignment_codes_in_hbm_slots_equal_oracle(oracle, monkeypatch):
     assert sorted(v[1] for v in got.dd_log.values()) == sorted(int(x) for x in vi)
 
 
+def test_alignment_panels_of_2048_columns_equal_oracle(oracle):
+    """Second alignments beyond 2047 columns: the alignment DP runs in panels of 64 x 32 columns with the panel's last column
+    handed on through the edge array, the folding of that width takes the workgroup form, and every set-up kernel sees rows
+    of more than 2048 cells.  The model kernels stop at 2047 nt, so matching and base-pairing rows are supplied
+    (--align-aux / --fold-aux paths, on both sides): three sequences of 2 150, 2 090 and 140 nt, rows near the diagonal.
+    Output and iteration log must be the oracle's (t_max bounds its time)."""
+    from dafs_amd import pipeline
+    rng = np.random.default_rng(91)
+    lens = [2150, 2090, 140]
+    seqs = ["".join(rng.choice(list("ACGU"), L)) for L in lens]
+    names = ["s%d" % k for k in range(3)]
+    bp = []
+    for L in lens:   # a few stems per sequence: pairs (i, j) with runs of stacked neighbours
+        rows = [[] for _ in range(L)]
+        for _ in range(max(2, L // 60)):
+            i0 = int(rng.integers(0, L - 30)); span = int(rng.integers(8, 28)); n = int(rng.integers(3, 7))
+            for d in range(n):
+                i, j = i0 + d, i0 + span - d
+                if j - i >= 4 and j < L and not any(c == j for c, _ in rows[i]):
+                    rows[i].append((j, np.float32(0.25 + 0.7 * rng.random())))
+        for r in rows:
+            r.sort()
+        rp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.uint32)
+        bp.append((rp, np.array([c for r in rows for c, _ in r], np.uint32), np.array([v for r in rows for _, v in r], np.float32)))
+    def rows_for(x, y):
+        Lx, Ly = lens[x], lens[y]
+        rp, col, val = [0], [], []
+        for i in range(Lx):
+            c0 = int(i * Ly / Lx)
+            ks = sorted(set(int(k) for k in (c0 + rng.integers(-2, 3, size=2)) if 0 <= k < Ly))
+            for k in ks:
+                col.append(k); val.append(np.float32(0.05 + 0.4 * rng.random()))
+            rp.append(len(col))
+        return np.array(rp, np.uint32), np.array(col, np.uint32), np.array(val, np.float32)
+    rows_of = {(x, y): rows_for(x, y) for x in range(3) for y in range(x + 1, 3)}
+    order = [(x, y) for x in range(3) for y in range(x + 1, 3)]
+    mp = (np.array([len(rows_of[p][1]) for p in order], np.uint32), np.concatenate([rows_of[p][0] for p in order]),
+          np.concatenate([rows_of[p][1] for p in order]), np.concatenate([rows_of[p][2] for p in order]))
+    kw = dict(t_max=6, th_s=0.1)
+    pl = oracle.pipeline(names, seqs, oracle.params(fold_model=1, align_model=2, th_s1=0.1, **kw), bp=bp, mp=lambda x, y: rows_of[(x, y)])
+    pl.phase1(); pl.phase2()
+    want = pl.output()
+    it, vi = pl.dd_log()
+    pl.close()
+    got = pipeline.run(names, seqs, bp=bp, mp=mp, skip_uncoupled_folds=False, **kw)
+    assert max(max(d) for d in got.dd_dims.values()) > 2047
+    assert got.output == want
+    assert sorted(v[0] for v in got.dd_log.values()) == sorted(int(x) for x in it)
+    assert sorted(v[1] for v in got.dd_log.values()) == sorted(int(x) for x in vi)
+
+
 @pytest.mark.parametrize("density", [0.03, 0.3])
 def test_workgroup_folding_form_equals_oracle(oracle, monkeypatch, density):
     """DAFS_HIP_DD_WG=2 gives every folder of a split node the workgroup form of the folding DP that only foldings beyond
