@@ -283,10 +283,13 @@ def main():
     if world > 1 or os.environ.get("DAFS_BENCH_FORCE_EXCHANGE") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        import datetime
+        # a collective that a rank never joins ends the run after three minutes instead of the backend's default half hour
+        limit = datetime.timedelta(seconds=180)
         if world == 1:
-            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1, timeout=limit)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
 
     # ---- device-resident inputs (torch = allocator + stream only) ----
     codes = np.concatenate([capi.encode(s) for s in seqs])
