@@ -998,7 +998,11 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
   const uint32_t npanels = MODE == 1 ? 1u : (L2 + 64u * W) / (64u * W);  // columns 0 .. L2
   const size_t panel_words = ((size_t)L1 + 63) * W * 64;                  // inputs of one panel
   const bool lane0 = lane == 0;
-  float P[W], Pc[W], Qc[W], np[W], nq[W];
+  // Input register sets.  AHEAD = how many steps ahead a step's inputs are fetched: the narrow LDS-table forms fetch three
+  // steps ahead into four sets that take turns (a step of ~0.2 us is shorter than the trip to L2, and a wait at the end of
+  // every step for the loads issued at its start made the step exactly that trip long); the wide forms keep one step.
+  constexpr int AHEAD = (MODE == 1 && W <= 8) ? 3 : 1;
+  float P[W], B[AHEAD + 1][2][W];
   float score = 0.0f;
   for (uint32_t panel = 0; panel < npanels; ++panel) {
     const int kbase = (int)(panel * 64u * W);
@@ -1009,14 +1013,19 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
     DD_GLB const float* ein = edge + (panel & 1u ? 0 : (L1 + 2));   // written by the panel before
     DD_GLB float* eout = edge + (panel & 1u ? (L1 + 2) : 0);
 #pragma unroll
-    for (int c = 0; c < W; ++c) { P[c] = 0.0f; Pc[c] = ps[(size_t)c * 64 + lane]; Qc[c] = qs[(size_t)c * 64 + lane]; np[c] = 0.0f; nq[c] = 0.0f; }
+    for (int c = 0; c < W; ++c) P[c] = 0.0f;
     float last = 0.0f, leftprev = 0.0f;
     const uint32_t lanes_on = (L2 - (uint32_t)kbase) / W + 1 < 64u ? (L2 - (uint32_t)kbase) / W + 1 : 64u;  // lanes beyond column L2 have nothing to do
     const int nsteps = (int)L1 + (int)lanes_on - 1;
     float e_cur = 0.0f;  // lane 0: dp[row of this step][kbase - 1]
     if (!first) e_cur = ein[1];
 #pragma unroll
-    for (int c = 0; c < W; ++c) asm volatile("" : "+v"(Pc[c]), "+v"(Qc[c]));  // nothing pending at the loop header (see nuss_wave_reg)
+    for (int a = 0; a < AHEAD; ++a)   // the inputs of steps 0 .. AHEAD-1
+#pragma unroll
+      for (int c = 0; c < W; ++c) {
+        B[a][0][c] = a < nsteps ? ps[((size_t)a * W + c) * 64 + lane] : 0.0f;
+        B[a][1][c] = a < nsteps ? qs[((size_t)a * W + c) * 64 + lane] : 0.0f;
+      }
     asm volatile("" : "+v"(e_cur));
     // Straight-line steps: every cell is computed and then replaced by what its place in the grid says (outside the
     // envelope: lowest(); column 0: 0; rows outside the grid: unchanged), and the codes of the lane's W cells -- consecutive
@@ -1031,21 +1040,22 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
     DD_GLB const v2u* envp = (DD_GLB const v2u*)env + (i + 1 + 64);        // envelope of row i + 1
     DD_LDS uint32_t* word = tr_l + (int)RW * i + (k0 >> 4);                // MODE 1: the lane's cells in row i (never touched while i < 1)
     DD_GLB unsigned long long* slot = tr_g + (ptrdiff_t)i * 64 + lane;     // MODE 2: the lane's slot of row i
-    DD_GLB const float* pnext = ps + (size_t)W * 64 + lane;                // inputs of step 1
-    DD_GLB const float* qnext = qs + (size_t)W * 64 + lane;
+    DD_GLB const float* pnext = ps + (size_t)AHEAD * W * 64 + lane;        // inputs of step AHEAD
+    DD_GLB const float* qnext = qs + (size_t)AHEAD * W * 64 + lane;
     int lo = 1, hi = 0;
     if (lane == 0) { const v2u e1 = ((DD_GLB const v2u*)env)[1 + 64]; lo = (int)e1.x; hi = (int)e1.y; }  // row 1
     asm volatile("" : "+v"(lo), "+v"(hi));
-    for (int s = 0; s < nsteps; ++s) {
+    // One step: cp / cq hold its inputs, xp / xq receive those of step s + AHEAD.
+    auto step = [&](int s, float (&cp)[W], float (&cq)[W], float (&xp)[W], float (&xq)[W]) __attribute__((always_inline)) {
       // the envelope of the next row first: loads return in order, so the wait for it at the end of the step leaves the
-      // prefetch of the next step's inputs in flight
+      // prefetch of the later steps' inputs in flight
       const v2u ne = *envp;
       float e_next = 0.0f;
       if (MODE == 2 && !first) e_next = ein[(uint32_t)(s + 2) <= L1 ? s + 2 : (int)L1];  // lane 0's left neighbour of the next step
       __builtin_amdgcn_sched_barrier(0);
-      if (s + 1 < nsteps) {
+      if (s + AHEAD < nsteps) {
 #pragma unroll
-        for (int c = 0; c < W; ++c) { np[c] = pnext[c * 64]; nq[c] = qnext[c * 64]; }
+        for (int c = 0; c < W; ++c) { xp[c] = pnext[c * 64]; xq[c] = qnext[c * 64]; }
       }
       __builtin_amdgcn_sched_barrier(0);
       const bool rowv = i >= 1 && i <= (int)L1;
@@ -1059,8 +1069,8 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
       for (int c = 0; c < W; ++c) {
         const int k = k0 + c;
         const float up = P[c];
-        float cand = diag + Pc[c] - th;  // needleman_wunsch.cpp:281-283
-        cand = cand + Qc[c];
+        float cand = diag + cp[c] - th;  // needleman_wunsch.cpp:281-283
+        cand = cand + cq[c];
         const bool m1 = cand < up;
         const float v1 = m1 ? up : cand;
         const bool m2 = v1 < left;
@@ -1090,8 +1100,25 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
       lo = (int)ne.x; hi = (int)ne.y;
       e_cur = e_next;
       ++i; ++envp; word += RW; slot += 64; pnext += W * 64; qnext += W * 64;
-#pragma unroll
-      for (int c = 0; c < W; ++c) { Pc[c] = np[c]; Qc[c] = nq[c]; }
+    };
+    // the sets take turns: step s reads set s mod (AHEAD + 1) and fills the set the step before it has just used up
+    int s = 0;
+    if constexpr (AHEAD == 3) {
+      for (; s + 3 < nsteps; s += 4) {
+        step(s, B[0][0], B[0][1], B[3][0], B[3][1]);
+        step(s + 1, B[1][0], B[1][1], B[0][0], B[0][1]);
+        step(s + 2, B[2][0], B[2][1], B[1][0], B[1][1]);
+        step(s + 3, B[3][0], B[3][1], B[2][0], B[2][1]);
+      }
+      if (s < nsteps) step(s, B[0][0], B[0][1], B[3][0], B[3][1]);
+      if (s + 1 < nsteps) step(s + 1, B[1][0], B[1][1], B[0][0], B[0][1]);
+      if (s + 2 < nsteps) step(s + 2, B[2][0], B[2][1], B[1][0], B[1][1]);
+    } else {
+      for (; s + 1 < nsteps; s += 2) {
+        step(s, B[0][0], B[0][1], B[1][0], B[1][1]);
+        step(s + 1, B[1][0], B[1][1], B[0][0], B[0][1]);
+      }
+      if (s < nsteps) step(s, B[0][0], B[0][1], B[1][0], B[1][1]);
     }
     if (panel + 1 < npanels) __threadfence_block();  // the edge column is in place before lane 0 of the next panel reads it
     else {
