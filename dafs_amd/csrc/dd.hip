@@ -262,13 +262,13 @@ __device__ void nuss_traceback_span(uint32_t L, const uint32_t* __restrict__ T_,
       const unsigned long long m = __ballot(probe != 1u);
       const int r = m ? (int)__ffsll((long long)m) - 1 : 63;
       i += 1 + r;
-      t = (uint32_t)__shfl((int)probe, r);
+      t = (uint32_t)__builtin_amdgcn_readlane((int)probe, r);
     } else if (t == 2) {
       const uint32_t probe = code(i, j - 1 - lane);
       const unsigned long long m = __ballot(probe != 2u);
       const int r = m ? (int)__ffsll((long long)m) - 1 : 63;
       j -= 1 + r;
-      t = (uint32_t)__shfl((int)probe, r);
+      t = (uint32_t)__builtin_amdgcn_readlane((int)probe, r);
     } else if (t == 3) {
       const uint32_t probe = code(i + 1 + lane, j - 1 - lane);
       const unsigned long long m = __ballot(probe != 3u);
@@ -276,7 +276,7 @@ __device__ void nuss_traceback_span(uint32_t L, const uint32_t* __restrict__ T_,
       if (lane == 0) ss[i] = (uint32_t)j;
       if (lane < r) ss[i + 1 + lane] = (uint32_t)(j - 1 - lane);
       i += 1 + r; j -= 1 + r;
-      t = (uint32_t)__shfl((int)probe, r);
+      t = (uint32_t)__builtin_amdgcn_readlane((int)probe, r);
     } else {
       const int k = i + (int)t - 3;
       if (lane == 0) {
@@ -961,20 +961,20 @@ __device__ bool nw_traceback_wave(uint32_t L1, uint32_t L2, const uint32_t* tr_,
       const int r = m ? (int)__ffsll((long long)m) - 1 : 63;  // cells of the run after the first (at most 64 cells a turn)
       if (lane <= r) al[i - 1 - lane] = (uint32_t)(k - 1 - lane);
       i -= 1 + r; k -= 1 + r;
-      t = m ? (uint32_t)__shfl((int)probe, r) : (uint32_t)__builtin_amdgcn_readfirstlane((int)code(i, k));
+      t = m ? (uint32_t)__builtin_amdgcn_readlane((int)probe, r) : (uint32_t)__builtin_amdgcn_readfirstlane((int)code(i, k));
     } else if (t == 2u) {  // X run: rows i, i-1, ... of column k
       probe = code(i - 1 - lane, k);
       m = __ballot(probe != 2u);
       const int r = m ? (int)__ffsll((long long)m) - 1 : 63;
       if (lane <= r) al[i - 1 - lane] = DD_NONE;
       i -= 1 + r;
-      t = m ? (uint32_t)__shfl((int)probe, r) : (uint32_t)__builtin_amdgcn_readfirstlane((int)code(i, k));
+      t = m ? (uint32_t)__builtin_amdgcn_readlane((int)probe, r) : (uint32_t)__builtin_amdgcn_readfirstlane((int)code(i, k));
     } else if (t == 3u) {  // Y run
       probe = code(i, k - 1 - lane);
       m = __ballot(probe != 3u);
       const int r = m ? (int)__ffsll((long long)m) - 1 : 63;
       k -= 1 + r;
-      t = m ? (uint32_t)__shfl((int)probe, r) : (uint32_t)__builtin_amdgcn_readfirstlane((int)code(i, k));
+      t = m ? (uint32_t)__builtin_amdgcn_readlane((int)probe, r) : (uint32_t)__builtin_amdgcn_readfirstlane((int)code(i, k));
     } else return false;
   }
   return i == 0 && k == 0;
