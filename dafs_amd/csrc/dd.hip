@@ -1003,6 +1003,7 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
   // every step for the loads issued at its start made the step exactly that trip long); the wide forms keep one step.
   constexpr int AHEAD = (MODE == 1 && W <= 8) ? 3 : 1;
   float P[W], B[AHEAD + 1][2][W];
+  v2u E[AHEAD + 1];  // the envelope {lo, hi} of the row each set's step is on: fetched as far ahead as the inputs
   float score = 0.0f;
   for (uint32_t panel = 0; panel < npanels; ++panel) {
     const int kbase = (int)(panel * 64u * W);
@@ -1026,6 +1027,8 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
         B[a][0][c] = a < nsteps ? ps[((size_t)a * W + c) * 64 + lane] : 0.0f;
         B[a][1][c] = a < nsteps ? qs[((size_t)a * W + c) * 64 + lane] : 0.0f;
       }
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) E[a] = ((DD_GLB const v2u*)env)[1 - lane + a + 64];  // rows of steps 0 .. AHEAD-1 (the padding makes every index valid)
     asm volatile("" : "+v"(e_cur));
     // Straight-line steps: every cell is computed and then replaced by what its place in the grid says (outside the
     // envelope: lowest(); column 0: 0; rows outside the grid: unchanged), and the codes of the lane's W cells -- consecutive
@@ -1037,19 +1040,15 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
     const uint32_t RW = dd_nwtab_row_words(L2);
     const uint32_t sh = ((uint32_t)k0 & 15u) * 2u;
     int i = 1 - lane;                                                      // row of step 0
-    DD_GLB const v2u* envp = (DD_GLB const v2u*)env + (i + 1 + 64);        // envelope of row i + 1
+    DD_GLB const v2u* envp = (DD_GLB const v2u*)env + (i + AHEAD + 64);    // envelope of the row of step AHEAD
     DD_LDS uint32_t* word = tr_l + (int)RW * i + (k0 >> 4);                // MODE 1: the lane's cells in row i (never touched while i < 1)
     DD_GLB unsigned long long* slot = tr_g + (ptrdiff_t)i * 64 + lane;     // MODE 2: the lane's slot of row i
     DD_GLB const float* pnext = ps + (size_t)AHEAD * W * 64 + lane;        // inputs of step AHEAD
     DD_GLB const float* qnext = qs + (size_t)AHEAD * W * 64 + lane;
-    int lo = 1, hi = 0;
-    if (lane == 0) { const v2u e1 = ((DD_GLB const v2u*)env)[1 + 64]; lo = (int)e1.x; hi = (int)e1.y; }  // row 1
-    asm volatile("" : "+v"(lo), "+v"(hi));
     // One step: cp / cq hold its inputs, xp / xq receive those of step s + AHEAD.
-    auto step = [&](int s, float (&cp)[W], float (&cq)[W], float (&xp)[W], float (&xq)[W]) __attribute__((always_inline)) {
-      // the envelope of the next row first: loads return in order, so the wait for it at the end of the step leaves the
-      // prefetch of the later steps' inputs in flight
-      const v2u ne = *envp;
+    auto step = [&](int s, float (&cp)[W], float (&cq)[W], const v2u& ce, float (&xp)[W], float (&xq)[W], v2u& xe) __attribute__((always_inline)) {
+      const int lo = (int)ce.x, hi = (int)ce.y;
+      if (s + AHEAD < nsteps) xe = *envp;
       float e_next = 0.0f;
       if (MODE == 2 && !first) e_next = ein[(uint32_t)(s + 2) <= L1 ? s + 2 : (int)L1];  // lane 0's left neighbour of the next step
       __builtin_amdgcn_sched_barrier(0);
@@ -1059,6 +1058,9 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
       }
       __builtin_amdgcn_sched_barrier(0);
       const bool rowv = i >= 1 && i <= (int)L1;
+      const bool some = hi >= lo;                                   // an empty range (hi < lo: rows outside the grid) admits no k
+      const int lo_e = some ? lo : 0x7fffffff;
+      const uint32_t span = some ? (uint32_t)(hi - lo) : 0u;
       float recv = wave_shr1(last);  // lane 0 of the first panel owns column 0, which takes nothing from its left
       if (MODE == 2 && !first) recv = lane0 ? e_cur : recv;
       float diag = leftprev;
@@ -1076,11 +1078,11 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
         const bool m2 = v1 < left;
         const float v2 = m2 ? left : v1;
         const uint32_t t = m2 ? 3u : (m1 ? 2u : 1u);
-        const bool inside = k >= lo && k <= hi;  // empty outside the rows of the grid
+        const bool inside = (uint32_t)(k - lo_e) <= span;  // lo <= k <= hi in one compare; empty outside the rows of the grid
         v = inside ? v2 : -FLT_MAX;
         if (c == 0) v = (lane0 && first) ? 0.0f : v;  // column 0
         v = rowv ? v : up;                       // rows outside the grid: the cell keeps what it held (row 0 / the last row)
-        codes |= (unsigned long long)(inside ? t : 0u) << (2 * c);
+        codes |= (unsigned long long)(inside ? t : 0u) << (2 * c);  // (cells beyond column L2 must leave the table's next row alone)
         diag = up;
         P[c] = v;
         left = v;
@@ -1097,7 +1099,6 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
       }
       leftprev = recv;
       last = v;
-      lo = (int)ne.x; hi = (int)ne.y;
       e_cur = e_next;
       ++i; ++envp; word += RW; slot += 64; pnext += W * 64; qnext += W * 64;
     };
@@ -1105,20 +1106,20 @@ __device__ float nw_wave_reg(uint32_t L1_, uint32_t L2_, const float* ps_, const
     int s = 0;
     if constexpr (AHEAD == 3) {
       for (; s + 3 < nsteps; s += 4) {
-        step(s, B[0][0], B[0][1], B[3][0], B[3][1]);
-        step(s + 1, B[1][0], B[1][1], B[0][0], B[0][1]);
-        step(s + 2, B[2][0], B[2][1], B[1][0], B[1][1]);
-        step(s + 3, B[3][0], B[3][1], B[2][0], B[2][1]);
+        step(s, B[0][0], B[0][1], E[0], B[3][0], B[3][1], E[3]);
+        step(s + 1, B[1][0], B[1][1], E[1], B[0][0], B[0][1], E[0]);
+        step(s + 2, B[2][0], B[2][1], E[2], B[1][0], B[1][1], E[1]);
+        step(s + 3, B[3][0], B[3][1], E[3], B[2][0], B[2][1], E[2]);
       }
-      if (s < nsteps) step(s, B[0][0], B[0][1], B[3][0], B[3][1]);
-      if (s + 1 < nsteps) step(s + 1, B[1][0], B[1][1], B[0][0], B[0][1]);
-      if (s + 2 < nsteps) step(s + 2, B[2][0], B[2][1], B[1][0], B[1][1]);
+      if (s < nsteps) step(s, B[0][0], B[0][1], E[0], B[3][0], B[3][1], E[3]);
+      if (s + 1 < nsteps) step(s + 1, B[1][0], B[1][1], E[1], B[0][0], B[0][1], E[0]);
+      if (s + 2 < nsteps) step(s + 2, B[2][0], B[2][1], E[2], B[1][0], B[1][1], E[1]);
     } else {
       for (; s + 1 < nsteps; s += 2) {
-        step(s, B[0][0], B[0][1], B[1][0], B[1][1]);
-        step(s + 1, B[1][0], B[1][1], B[0][0], B[0][1]);
+        step(s, B[0][0], B[0][1], E[0], B[1][0], B[1][1], E[1]);
+        step(s + 1, B[1][0], B[1][1], E[1], B[0][0], B[0][1], E[0]);
       }
-      if (s < nsteps) step(s, B[0][0], B[0][1], B[1][0], B[1][1]);
+      if (s < nsteps) step(s, B[0][0], B[0][1], E[0], B[1][0], B[1][1], E[1]);
     }
     if (panel + 1 < npanels) __threadfence_block();  // the edge column is in place before lane 0 of the next panel reads it
     else {
