@@ -2311,23 +2311,29 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     // multiplier updates (:1121-1254), every cell touched by exactly one lane
     uint32_t viol = 0;
     for (uint32_t i = tid; i < L1; i += nt) {
-      const uint32_t j = nd.x[i];
+      // The loads of a row's x and z cell are issued level by level, whether the row has such a cell or not (the indices of
+      // the missing ones point at cell 0 of the row): the chain x -> map -> count -> multiplier, followed by the same chain
+      // for z, was a dozen dependent trips to L2 per iteration.
+      const uint32_t j = nd.x[i], kz = nd.z[i];
+      const uint32_t pe0 = nd.px_ptr[i], pe1 = nd.px_ptr[i + 1], ce0 = nd.cz_ptr[i], ce1 = nd.cz_ptr[i + 1];
+      const size_t ox = (size_t)i * L1 + (j != DD_NONE ? j : 0u), oz = (size_t)i * L2 + (kz != DD_NONE ? kz : 0u);
+      const int32_t idx = nd.xmap[ox], idz = nd.zmap[oz];
+      const float qx0 = nd.q_x[ox], px0 = nd.p_x[ox], qz0 = nd.q_z[oz];
+      const int tcx0 = nd.tx[idx >= 0 ? idx : 0], tcz0 = nd.tz[idz >= 0 ? idz : 0];
       if (j != DD_NONE) {
-        const int32_t id = nd.xmap[(size_t)i * L1 + j];
-        const int tc = id >= 0 ? nd.tx[id] : 0;
+        const int tc = idx >= 0 ? tcx0 : 0;
         if (tc != 1) {
           ++viol;
-          const size_t o = (size_t)i * L1 + j;
-          const float qn = nd.q_x[o] - eta * (tc - 1);
-          nd.q_x[o] = qn;
+          const float qn = qx0 - eta * (tc - 1);
+          nd.q_x[ox] = qn;
           if (j >= i + 3) {
-            const float sv = w_x * (nd.p_x[o] - prm.th_s) - qn;
+            const float sv = w_x * (px0 - prm.th_s) - qn;
             if (nd.s_x) nd.s_x[fold_sidx(false, L1, Wx, i, j)] = sv;
             if (nd.s_xs) nd.s_xs[fold_sidx(true, L1, Wx, i, j)] = sv;
           }
         }
       }
-      for (uint32_t e = nd.px_ptr[i]; e < nd.px_ptr[i + 1]; ++e) {
+      for (uint32_t e = pe0; e < pe1; ++e) {
         if (!nd.cx_flag[e]) continue;
         const uint32_t jj = nd.px_j[e];
         const int tc = nd.tx[e];
@@ -2343,17 +2349,15 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
           }
         }
       }
-      const uint32_t kz = nd.z[i];
       if (kz != DD_NONE) {
-        const int32_t id = nd.zmap[(size_t)i * L2 + kz];
-        const int tc = id >= 0 ? nd.tz[id] : 0;
+        const int tc = idz >= 0 ? tcz0 : 0;
         if (tc > 1) ++viol;
-        const float v = nd.q_z[(size_t)i * L2 + kz] - eta * (1 - tc);
+        const float v = qz0 - eta * (1 - tc);
         const float qn = (0.0f < v) ? v : 0.0f;
-        nd.q_z[(size_t)i * L2 + kz] = qn;
+        nd.q_z[oz] = qn;
         nd.qz_s[nw_idx(L1, Wz, i + 1, kz + 1)] = qn;
       }
-      for (uint32_t e = nd.cz_ptr[i]; e < nd.cz_ptr[i + 1]; ++e) {
+      for (uint32_t e = ce0; e < ce1; ++e) {
         const uint32_t kk = nd.cz_k[e];
         if (kz != kk) {
           const int tc = nd.tz[e];
@@ -2367,22 +2371,25 @@ __global__ __launch_bounds__(DD_SOLVE_THREADS) void k_dd_solve(const dd_node* no
     }
     for (uint32_t k = (tid + nt / 2) % nt; k < L2; k += nt) {  // the upper half of the workgroup starts on y while the lower half is on x
       const uint32_t l = nd.y[k];
+      const uint32_t ye0 = nd.py_ptr[k], ye1 = nd.py_ptr[k + 1];
+      const size_t oy = (size_t)k * L2 + (l != DD_NONE ? l : 0u);
+      const int32_t idy = nd.ymap[oy];
+      const float qy0 = nd.q_y[oy], py0 = nd.p_y[oy];
+      const int tcy0 = nd.ty[idy >= 0 ? idy : 0];
       if (l != DD_NONE) {
-        const int32_t id = nd.ymap[(size_t)k * L2 + l];
-        const int tc = id >= 0 ? nd.ty[id] : 0;
+        const int tc = idy >= 0 ? tcy0 : 0;
         if (tc != 1) {
           ++viol;
-          const size_t o = (size_t)k * L2 + l;
-          const float qn = nd.q_y[o] - eta * (tc - 1);
-          nd.q_y[o] = qn;
+          const float qn = qy0 - eta * (tc - 1);
+          nd.q_y[oy] = qn;
           if (l >= k + 3) {
-            const float sv = w_y * (nd.p_y[o] - prm.th_s) - qn;
+            const float sv = w_y * (py0 - prm.th_s) - qn;
             if (nd.s_y) nd.s_y[fold_sidx(false, L2, Wy, k, l)] = sv;
             if (nd.s_ys) nd.s_ys[fold_sidx(true, L2, Wy, k, l)] = sv;
           }
         }
       }
-      for (uint32_t e = nd.py_ptr[k]; e < nd.py_ptr[k + 1]; ++e) {
+      for (uint32_t e = ye0; e < ye1; ++e) {
         if (!nd.cy_flag[e]) continue;
         const uint32_t ll = nd.py_l[e];
         const int tc = nd.ty[e];
