@@ -674,10 +674,10 @@ int nodes_result(dafs_hip_ctx* c, uint32_t handle, dafs_node_output* out, bool s
   if (out->z) memcpy(out->z, at(nd.z), (size_t)nd.L1 * 4);
   memcpy(&score, at(nd.score), 4);
   memcpy(info, at(nd.info), sizeof info);
-  if (stamps && nd.fold_fast & (64u | 128u)) {
+  if (stamps && nd.fold_fast & (16u | 32u | 64u | 128u)) {
     uint32_t sy[8] = {0};
     if (!hip_check(hipMemcpy(sy, nd.sync, sizeof sy, hipMemcpyDeviceToHost)))
-      fprintf(stderr, "dd node L1=%u L2=%u folders (workgroup form) | us: x-dp %.0f y-dp %.0f tracebacks %.0f\n", nd.L1, nd.L2, sy[5] / 100.0, sy[6] / 100.0, sy[7] / 100.0);
+      fprintf(stderr, "dd node L1=%u L2=%u folders | us: x-dp %.0f y-dp %.0f tracebacks %.0f\n", nd.L1, nd.L2, sy[5] / 100.0, sy[6] / 100.0, sy[7] / 100.0);
   }
   if (stamps)
     fprintf(stderr, "dd node L1=%u L2=%u n=%u+%u ncbp=%u iters=%u slow-xy=%u+%u | us: x-dp %.0f x-traceback %.0f wait %.0f cbp %.0f update %.0f tail %.0f | y %.0f z %.0f flags %x\n", nd.L1,

@@ -1960,12 +1960,17 @@ __device__ __forceinline__ void dd_folder(const dd_node& nd, const dd_params& pr
       if (tid == 0) s_slow = 0;
       __syncthreads();
       bool slow = true;
+      const unsigned long long tf0 = prm.stamps ? wall_clock64() : 0ull;
       const float sc = nuss_span_mw(L, isx ? nd.s_xs : nd.s_ys, trbp, tri, cvl, ckl, lck, wave, lane, &slow);
       if (slow && lane == 0) atomicOr(&s_slow, 1u);
       __syncthreads();
       if (wave == 0) {
+        const unsigned long long tf1 = prm.stamps ? wall_clock64() : 0ull;
         if (!s_slow) nuss_traceback_fast(L, trbp, trb_g, lck, ss, (uint32_t*)P, lane);
-        if (lane == 0) s_fscore = sc;
+        if (lane == 0) {
+          s_fscore = sc;
+          if (prm.stamps) { nd.sync[isx ? 5 : 6] += (uint32_t)(tf1 - tf0); nd.sync[7] += (uint32_t)(wall_clock64() - tf1); }  // DP of x / y, tracebacks of both
+        }
       }
       __syncthreads();
       gave_up = s_slow != 0;
